@@ -1,0 +1,171 @@
+/*
+ * lqmpc.h -- C ABI of the MI355X batched LQ-MPC box-QP solver (liblqmpc_hip.so).
+ *
+ * The reference (lcrekko/lq_mpc) has no FFI: its operator boundary for this path is two
+ * Python classes.  Each entry point below names the reference interface it replaces:
+ *
+ *   lqmpc_solve_batch    <- LQ_MPC_Controller.solve          /root/reference/utils_class.py:48-91
+ *                           (one call per instance there; Bsz instances per call here)
+ *   lqmpc_rollout_batch  <- LQ_MPC_Simulator.simulate        /root/reference/utils_class.py:245-285
+ *   lqmpc_max_vn_batch   <- the M_V loops of
+ *                           LQ_RDP_Behavior_Multiple.data_generation
+ *                                                            /root/reference/utils_class.py:813-824, 896-907
+ *                           and LQ_RDP_Behavior.OL_energy_bound  utils_class.py:439-466
+ *
+ * Problem solved per instance (utils_class.py:59-91; n = N*nu; no 1/2 factor):
+ *   min  sum_{i=0}^{N-2} |x_{i+1}-xref_i|^2_Q + |x_N-xref_{N-1}|^2_P + sum_{i=0}^{N-1} |u_i-uref_i|^2_R
+ *   s.t. x_{i+1} = A x_i + B u_i,   lb <= u_i <= ub     (F_u u_i <= 1 with box rows, line 81)
+ *   u_0 = u*[:,0],  V_N = cost* + x0' Q x0               (line 91)
+ *
+ * Data layout.  Per-instance arrays are instance-minor ("SoA", the layout of the reference's
+ * error_{A,B}_f.npy files, utils_class.py:749-750):
+ *     A[(r*nx + c)*Bsz + b]   B[(r*nu + k)*Bsz + b]   x0[a*Bsz + b]
+ *     u0[k*Bsz + b]  VN[b]  JT[b]  MV[b]  status[b]  iters[b]
+ *     X[(a*(T+1) + t)*Bsz + b]   U[(k*T + t)*Bsz + b]            (optional trajectories)
+ * Shared by the whole batch (plain row-major, always HOST pointers, copied by the call):
+ *     Q (nx,nx)  R (nu,nu)  P (nx,nx)  lb (nu)  ub (nu)
+ *     x_ref (nx,N) / u_ref (nu,N) as the reference passes them; NULL means zeros
+ *     A_true (nx,nx), B_true (nx,nu) when true_per_instance == 0
+ *     x0s (nx,K): the K initial states of lqmpc_max_vn_batch
+ * All floating point is IEEE fp64, as in the reference.
+ *
+ * Two flavours of every batched call:
+ *   lqmpc_*_batch      per-instance pointers are HOST memory; the call copies in, runs, copies
+ *                      out and returns when the results are in the caller's buffers.
+ *   lqmpc_*_batch_dev  per-instance pointers are DEVICE memory on the handle's GPU; the call
+ *                      enqueues on the handle's stream and returns (use lqmpc_sync).
+ *
+ * Errors: every call returns 0 on success or a negative lqmpc_error; nothing is thrown
+ * across the ABI.  lqmpc_last_error() gives a thread-local message.  Per instance,
+ * status[b] is 0 converged, 1 iteration cap reached, 2 non-finite data.  The QP is always
+ * feasible and strictly convex (R > 0, non-empty box), so "infeasible" cannot occur.
+ *
+ * Threading: a handle is bound to one device and one stream and is not thread-safe;
+ * distinct handles may be used from distinct threads.
+ */
+#ifndef LQMPC_H
+#define LQMPC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lqmpc_handle lqmpc_handle;
+
+enum lqmpc_error {
+    LQMPC_OK = 0,
+    LQMPC_ERR_BAD_ARG = -1,      /* NULL pointer, non-positive size, empty box, dims over the limits */
+    LQMPC_ERR_HIP = -2,          /* a HIP runtime call failed (message in lqmpc_last_error) */
+    LQMPC_ERR_NO_DEVICE = -3,    /* no usable GPU */
+    LQMPC_ERR_ALLOC = -4,        /* device or host allocation failed */
+    LQMPC_ERR_UNSUPPORTED = -5   /* requested kernel variant not built for these dims */
+};
+
+/* Which kernel family runs the batch. */
+enum lqmpc_kernel {
+    LQMPC_KERNEL_AUTO = 0,       /* register-resident specialisation when built for (nx,nu,N), else generic */
+    LQMPC_KERNEL_GENERIC = 1,    /* any dims up to the limits; one instance per lane, workspace in HBM */
+    LQMPC_KERNEL_SPECIALIZED = 2 /* fail with LQMPC_ERR_UNSUPPORTED if no specialisation exists */
+};
+
+typedef struct lqmpc_options {
+    double eps;        /* relative tolerance on complementarity gap and dual residual (default 1e-12) */
+    double tau;        /* fraction-to-the-boundary of the interior-point step (default 0.999) */
+    double z0_scale;   /* initial multipliers = z0_scale * |q|_inf (default 0.1) */
+    int32_t max_iter;  /* interior-point iteration cap per QP (default 50) */
+    int32_t polish;    /* 1: finish with an exact solve on the identified active set (default 1) */
+    int32_t kernel;    /* enum lqmpc_kernel (default AUTO) */
+    int32_t reserved;
+} lqmpc_options;
+
+/* Limits of this build. */
+#define LQMPC_MAX_NX 16
+#define LQMPC_MAX_NU 8
+#define LQMPC_MAX_N  64
+#define LQMPC_MAX_NVAR 128   /* n = N*nu */
+
+const char *lqmpc_version(void);
+const char *lqmpc_last_error(void);
+/* Number of GPUs the HIP runtime sees (0 if none; never fails). */
+int lqmpc_device_count(void);
+
+/* Handle life cycle.  lqmpc_create makes its own stream; lqmpc_create_on_stream borrows a
+ * hipStream_t (passed as void*, may be NULL for the default stream). */
+int lqmpc_create(int device, lqmpc_handle **out);
+int lqmpc_create_on_stream(int device, void *hip_stream, lqmpc_handle **out);
+int lqmpc_destroy(lqmpc_handle *h);
+int lqmpc_sync(lqmpc_handle *h);
+
+void lqmpc_default_options(lqmpc_options *opt);
+int lqmpc_set_options(lqmpc_handle *h, const lqmpc_options *opt);
+int lqmpc_get_options(const lqmpc_handle *h, lqmpc_options *opt);
+
+/* 1 if a register-resident specialisation for (nx,nu,N) is compiled in, else 0. */
+int lqmpc_has_specialization(int nx, int nu, int N);
+/* Name of the kernel the last batched call on this handle launched (for logs/profiles). */
+const char *lqmpc_last_kernel(const lqmpc_handle *h);
+
+/* Pre-size the handle's device scratch so later calls do no allocation (e.g. before timing). */
+int lqmpc_reserve(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int T);
+
+/* ---- LQ_MPC_Controller.solve, batched (utils_class.py:48-91) ---- */
+int lqmpc_solve_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
+                      const double *A, const double *B,
+                      const double *Q, const double *R, const double *P,
+                      const double *lb, const double *ub,
+                      const double *x0, const double *x_ref, const double *u_ref,
+                      double *u0, double *VN, int32_t *status, int32_t *iters);
+int lqmpc_solve_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
+                          const double *dA, const double *dB,
+                          const double *Q, const double *R, const double *P,
+                          const double *lb, const double *ub,
+                          const double *dx0, const double *x_ref, const double *u_ref,
+                          double *du0, double *dVN, int32_t *dstatus, int32_t *diters);
+
+/* ---- LQ_MPC_Simulator.simulate, batched (utils_class.py:245-285) ----
+ * The model (A,B) drives the QP, the plant (A_true,B_true) drives the state.
+ * true_per_instance == 0: A_true/B_true are single HOST matrices shared by the batch
+ * (the reference's usage, utils_class.py:830-832); != 0: SoA arrays like A/B (host for the
+ * host flavour, device for the _dev flavour).  X, U, status, iters may be NULL. */
+int lqmpc_rollout_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int T,
+                        const double *A, const double *B,
+                        const double *Q, const double *R, const double *P,
+                        const double *lb, const double *ub, const double *x0,
+                        const double *A_true, const double *B_true, int true_per_instance,
+                        const double *x_ref, const double *u_ref,
+                        double *JT, double *X, double *U, int32_t *status, int32_t *iters);
+int lqmpc_rollout_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int T,
+                            const double *dA, const double *dB,
+                            const double *Q, const double *R, const double *P,
+                            const double *lb, const double *ub, const double *dx0,
+                            const double *A_true, const double *B_true, int true_per_instance,
+                            const double *x_ref, const double *u_ref,
+                            double *dJT, double *dX, double *dU, int32_t *dstatus, int32_t *diters);
+
+/* ---- M_V = max_k V_N(x0s[:,k]) per instance (utils_class.py:816-824, 899-907) ---- */
+int lqmpc_max_vn_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int K,
+                       const double *A, const double *B,
+                       const double *Q, const double *R, const double *P,
+                       const double *lb, const double *ub, const double *x0s,
+                       const double *x_ref, const double *u_ref,
+                       double *MV, int32_t *status, int32_t *iters);
+int lqmpc_max_vn_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int K,
+                           const double *dA, const double *dB,
+                           const double *Q, const double *R, const double *P,
+                           const double *lb, const double *ub, const double *x0s,
+                           const double *x_ref, const double *u_ref,
+                           double *dMV, int32_t *dstatus, int32_t *diters);
+
+/* ---- timing on the handle's stream (hipEvents), for bench.py's roofline ----
+ * begin/end bracket any number of *_dev calls; end waits for the stream and returns the
+ * elapsed milliseconds between the two events. */
+int lqmpc_timer_begin(lqmpc_handle *h);
+int lqmpc_timer_end(lqmpc_handle *h, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LQMPC_H */

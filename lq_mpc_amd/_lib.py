@@ -1,0 +1,97 @@
+"""ctypes binding of liblqmpc_hip.so (the C ABI in include/lqmpc.h).
+
+The product path has no CPU fallback: if the HIP library cannot be loaded, or no GPU is
+visible when a solver handle is requested, this module raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblqmpc_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_D = ctypes.POINTER(ctypes.c_double)
+_I32 = ctypes.POINTER(ctypes.c_int32)
+_H = ctypes.c_void_p
+
+# every symbol include/lqmpc.h declares
+EXPORTS = [
+    "lqmpc_version", "lqmpc_last_error", "lqmpc_device_count",
+    "lqmpc_create", "lqmpc_create_on_stream", "lqmpc_destroy", "lqmpc_sync",
+    "lqmpc_default_options", "lqmpc_set_options", "lqmpc_get_options",
+    "lqmpc_has_specialization", "lqmpc_last_kernel", "lqmpc_reserve",
+    "lqmpc_solve_batch", "lqmpc_solve_batch_dev",
+    "lqmpc_rollout_batch", "lqmpc_rollout_batch_dev",
+    "lqmpc_max_vn_batch", "lqmpc_max_vn_batch_dev",
+    "lqmpc_timer_begin", "lqmpc_timer_end",
+]
+
+
+class Options(ctypes.Structure):
+    _fields_ = [("eps", ctypes.c_double), ("tau", ctypes.c_double), ("z0_scale", ctypes.c_double),
+                ("max_iter", ctypes.c_int32), ("polish", ctypes.c_int32), ("kernel", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_SPECIALIZED = 0, 1, 2
+
+
+class LqmpcError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """hipcc build of the shared library for gfx950 (cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = ctypes.CDLL(LIB_PATH)
+    L.lqmpc_version.restype = ctypes.c_char_p
+    L.lqmpc_last_error.restype = ctypes.c_char_p
+    L.lqmpc_last_kernel.restype = ctypes.c_char_p
+    L.lqmpc_last_kernel.argtypes = [_H]
+    L.lqmpc_device_count.restype = ctypes.c_int
+    L.lqmpc_create.argtypes = [ctypes.c_int, ctypes.POINTER(_H)]
+    L.lqmpc_create_on_stream.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(_H)]
+    L.lqmpc_destroy.argtypes = [_H]
+    L.lqmpc_sync.argtypes = [_H]
+    L.lqmpc_default_options.argtypes = [ctypes.POINTER(Options)]
+    L.lqmpc_default_options.restype = None
+    L.lqmpc_set_options.argtypes = [_H, ctypes.POINTER(Options)]
+    L.lqmpc_get_options.argtypes = [_H, ctypes.POINTER(Options)]
+    L.lqmpc_has_specialization.argtypes = [ctypes.c_int] * 3
+    L.lqmpc_reserve.argtypes = [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int]
+    P = ctypes.c_void_p   # data pointers: host (numpy) or device (raw address), as void*
+    dims = [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64]
+    solve_args = dims + [P] * 14
+    L.lqmpc_solve_batch.argtypes = solve_args
+    L.lqmpc_solve_batch_dev.argtypes = solve_args
+    roll_args = dims + [ctypes.c_int] + [P] * 10 + [ctypes.c_int] + [P] * 7
+    L.lqmpc_rollout_batch.argtypes = roll_args
+    L.lqmpc_rollout_batch_dev.argtypes = roll_args
+    mv_args = dims + [ctypes.c_int] + [P] * 13
+    L.lqmpc_max_vn_batch.argtypes = mv_args
+    L.lqmpc_max_vn_batch_dev.argtypes = mv_args
+    L.lqmpc_timer_begin.argtypes = [_H]
+    L.lqmpc_timer_end.argtypes = [_H, ctypes.POINTER(ctypes.c_float)]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise LqmpcError(f"lqmpc error {rc}: {lib().lqmpc_last_error().decode()}")

@@ -1,0 +1,462 @@
+// lqmpc_api.hip -- host side of the C ABI declared in include/lqmpc.h: handle, argument checks,
+// shared-block packing, workspace management, kernel dispatch, host<->device staging.
+#include "lqmpc_common.h"
+#include "../../include/lqmpc.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace lqmpc {
+long long generic_ws_entries(int nx, int nu, int N);
+void launch_generic(const KParams &p, hipStream_t stream);
+// lqmpc_spec.hip: returns false when no specialisation is built for (nx,nu,N)
+bool spec_available(int nx, int nu, int N);
+bool launch_spec(const KParams &p, hipStream_t stream, const char **name);
+}  // namespace lqmpc
+
+using lqmpc::KParams;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(LQMPC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct lqmpc_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    lqmpc_options opt;
+    DevBuf shared, ws;
+    DevBuf stage[12];                // host-flavour staging (inputs and outputs)
+    std::vector<double> shared_host; // last uploaded shared block
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    const char *last_kernel = "none";
+};
+
+static int ensure(lqmpc_handle *h, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return 0;
+    if (b.p) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipFree(b.p));
+        b.p = nullptr; b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) { b.p = nullptr; return fail(LQMPC_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    b.cap = want;
+    return 0;
+}
+
+extern "C" {
+
+const char *lqmpc_version(void) { return "lqmpc-mi355x 0.1.0 (gfx950, fp64)"; }
+const char *lqmpc_last_error(void) { return g_err.c_str(); }
+
+int lqmpc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void lqmpc_default_options(lqmpc_options *opt)
+{
+    if (!opt) return;
+    opt->eps = 1e-12;
+    opt->tau = 0.999;
+    opt->z0_scale = 0.1;
+    opt->max_iter = 50;
+    opt->polish = 1;
+    opt->kernel = LQMPC_KERNEL_AUTO;
+    opt->reserved = 0;
+}
+
+int lqmpc_create_on_stream(int device, void *hip_stream, lqmpc_handle **out)
+{
+    if (!out) return fail(LQMPC_ERR_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(LQMPC_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(LQMPC_ERR_BAD_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    lqmpc_handle *h = new lqmpc_handle();
+    h->device = device;
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    lqmpc_default_options(&h->opt);
+    hipError_t e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e != hipSuccess) { delete h; return fail(LQMPC_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
+    *out = h;
+    return 0;
+}
+
+int lqmpc_create(int device, lqmpc_handle **out)
+{
+    int rc = lqmpc_create_on_stream(device, nullptr, out);
+    if (rc) return rc;
+    hipStream_t s;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) { lqmpc_destroy(*out); *out = nullptr; return fail(LQMPC_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    (*out)->stream = s;
+    (*out)->own_stream = true;
+    return 0;
+}
+
+int lqmpc_destroy(lqmpc_handle *h)
+{
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->shared.p) (void)hipFree(h->shared.p);
+    if (h->ws.p) (void)hipFree(h->ws.p);
+    for (auto &b : h->stage) if (b.p) (void)hipFree(b.p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int lqmpc_sync(lqmpc_handle *h)
+{
+    if (!h) return fail(LQMPC_ERR_BAD_ARG, "handle is NULL");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int lqmpc_set_options(lqmpc_handle *h, const lqmpc_options *opt)
+{
+    if (!h || !opt) return fail(LQMPC_ERR_BAD_ARG, "NULL argument");
+    if (!(opt->eps > 0.0 && opt->eps < 1.0)) return fail(LQMPC_ERR_BAD_ARG, "eps must be in (0,1)");
+    if (!(opt->tau > 0.0 && opt->tau < 1.0)) return fail(LQMPC_ERR_BAD_ARG, "tau must be in (0,1)");
+    if (!(opt->z0_scale > 0.0)) return fail(LQMPC_ERR_BAD_ARG, "z0_scale must be positive");
+    if (opt->max_iter < 1 || opt->max_iter > 1000) return fail(LQMPC_ERR_BAD_ARG, "max_iter must be in [1,1000]");
+    if (opt->kernel < LQMPC_KERNEL_AUTO || opt->kernel > LQMPC_KERNEL_SPECIALIZED) return fail(LQMPC_ERR_BAD_ARG, "unknown kernel selector");
+    h->opt = *opt;
+    return 0;
+}
+
+int lqmpc_get_options(const lqmpc_handle *h, lqmpc_options *opt)
+{
+    if (!h || !opt) return fail(LQMPC_ERR_BAD_ARG, "NULL argument");
+    *opt = h->opt;
+    return 0;
+}
+
+int lqmpc_has_specialization(int nx, int nu, int N) { return lqmpc::spec_available(nx, nu, N) ? 1 : 0; }
+
+const char *lqmpc_last_kernel(const lqmpc_handle *h) { return h ? h->last_kernel : "none"; }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+static int check_dims(int nx, int nu, int N, int64_t Bsz)
+{
+    if (nx < 1 || nu < 1 || N < 1 || Bsz < 1) return fail(LQMPC_ERR_BAD_ARG, "nx, nu, N and Bsz must be positive");
+    if (nx > LQMPC_MAX_NX || nu > LQMPC_MAX_NU || N > LQMPC_MAX_N || N * nu > LQMPC_MAX_NVAR) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "dims over the build limits (nx<=%d, nu<=%d, N<=%d, N*nu<=%d)", LQMPC_MAX_NX, LQMPC_MAX_NU,
+                 LQMPC_MAX_N, LQMPC_MAX_NVAR);
+        return fail(LQMPC_ERR_BAD_ARG, buf);
+    }
+    return 0;
+}
+
+static bool use_spec(const lqmpc_handle *h, int nx, int nu, int N)
+{
+    return h->opt.kernel != LQMPC_KERNEL_GENERIC && lqmpc::spec_available(nx, nu, N);
+}
+
+struct Call {
+    int nx, nu, N, T, K, mode, true_per_instance;
+    int64_t Bsz;
+    const double *Q, *R, *P, *lb, *ub, *x_ref, *u_ref, *At_sh, *Bt_sh, *x0s;
+};
+
+// Pack the batch-shared data, upload it (skipped when identical to the last upload), size the
+// workspace, fill the kernel parameter block.
+static int prepare(lqmpc_handle *h, const Call &c, KParams &p)
+{
+    int rc = check_dims(c.nx, c.nu, c.N, c.Bsz);
+    if (rc) return rc;
+    if (!c.Q || !c.R || !c.P || !c.lb || !c.ub) return fail(LQMPC_ERR_BAD_ARG, "Q, R, P, lb, ub must not be NULL");
+    for (int k = 0; k < c.nu; ++k)
+        if (!(c.ub[k] > c.lb[k]) || !std::isfinite(c.lb[k]) || !std::isfinite(c.ub[k]))
+            return fail(LQMPC_ERR_BAD_ARG, "every input needs a finite box with lb < ub");
+    HIP_TRY(hipSetDevice(h->device));
+    const int nx = c.nx, nu = c.nu, N = c.N;
+    std::vector<double> sh;
+    auto put = [&](const double *src, int count) {
+        int off = (int)sh.size();
+        sh.resize(sh.size() + count, 0.0);
+        if (src) memcpy(sh.data() + off, src, sizeof(double) * count);
+        return off;
+    };
+    memset(&p, 0, sizeof p);
+    p.so.Q = put(c.Q, nx * nx);
+    p.so.R = put(c.R, nu * nu);
+    p.so.P = put(c.P, nx * nx);
+    p.so.lb = put(c.lb, nu);
+    p.so.ub = put(c.ub, nu);
+    p.so.xref = put(c.x_ref, nx * N);
+    p.so.uref = put(c.u_ref, nu * N);
+    p.so.At = put(c.true_per_instance ? nullptr : c.At_sh, nx * nx);
+    p.so.Bt = put(c.true_per_instance ? nullptr : c.Bt_sh, nx * nu);
+    p.so.x0s = put(c.x0s, c.x0s ? nx * c.K : 1);
+    rc = ensure(h, h->shared, sh.size() * sizeof(double));
+    if (rc) return rc;
+    if (sh != h->shared_host) {
+        // the device copy may still be read by an earlier launch on this stream: order behind it
+        HIP_TRY(hipMemcpyAsync(h->shared.p, sh.data(), sh.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->shared_host.swap(sh);
+    }
+    p.nx = nx; p.nu = nu; p.N = N; p.n = N * nu;
+    p.T = c.T; p.K = c.K; p.mode = c.mode;
+    p.true_per_instance = c.true_per_instance;
+    p.has_ref = (c.x_ref || c.u_ref) ? 1 : 0;
+    p.max_iter = h->opt.max_iter; p.polish = h->opt.polish;
+    p.eps = h->opt.eps; p.tau = h->opt.tau; p.z0_scale = h->opt.z0_scale;
+    p.Bsz = c.Bsz;
+    p.sh = (const double *)h->shared.p;
+    if (h->opt.kernel == LQMPC_KERNEL_SPECIALIZED && !lqmpc::spec_available(nx, nu, N))
+        return fail(LQMPC_ERR_UNSUPPORTED, "no register-resident specialisation built for these dims");
+    if (!use_spec(h, nx, nu, N)) {
+        p.ws_stride = (c.Bsz + 63) / 64 * 64;
+        const size_t bytes = (size_t)lqmpc::generic_ws_entries(nx, nu, N) * (size_t)p.ws_stride * sizeof(double);
+        rc = ensure(h, h->ws, bytes);
+        if (rc) return rc;
+        p.ws = (double *)h->ws.p;
+    }
+    return 0;
+}
+
+static int launch(lqmpc_handle *h, const KParams &p)
+{
+    const char *name = "lqmpc_generic_kernel";
+    if (use_spec(h, p.nx, p.nu, p.N)) {
+        if (!lqmpc::launch_spec(p, h->stream, &name)) return fail(LQMPC_ERR_UNSUPPORTED, "specialisation launch failed");
+    } else {
+        lqmpc::launch_generic(p, h->stream);
+    }
+    h->last_kernel = name;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" {
+
+int lqmpc_reserve(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int T)
+{
+    if (!h) return fail(LQMPC_ERR_BAD_ARG, "handle is NULL");
+    int rc = check_dims(nx, nu, N, Bsz);
+    if (rc) return rc;
+    (void)T;
+    HIP_TRY(hipSetDevice(h->device));
+    rc = ensure(h, h->shared, 8192 * sizeof(double));
+    if (rc) return rc;
+    if (!use_spec(h, nx, nu, N)) {
+        const size_t stride = (size_t)(Bsz + 63) / 64 * 64;
+        rc = ensure(h, h->ws, (size_t)lqmpc::generic_ws_entries(nx, nu, N) * stride * sizeof(double));
+    }
+    return rc;
+}
+
+int lqmpc_solve_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, const double *dA, const double *dB,
+                          const double *Q, const double *R, const double *P, const double *lb, const double *ub,
+                          const double *dx0, const double *x_ref, const double *u_ref, double *du0, double *dVN,
+                          int32_t *dstatus, int32_t *diters)
+{
+    if (!h || !dA || !dB || !dx0 || !du0 || !dVN) return fail(LQMPC_ERR_BAD_ARG, "NULL argument");
+    Call c{nx, nu, N, 0, 0, lqmpc::MODE_SOLVE, 0, Bsz, Q, R, P, lb, ub, x_ref, u_ref, nullptr, nullptr, nullptr};
+    KParams p;
+    int rc = prepare(h, c, p);
+    if (rc) return rc;
+    p.A = dA; p.B = dB; p.x0 = dx0; p.u0 = du0; p.VN = dVN; p.status = dstatus; p.iters = diters;
+    return launch(h, p);
+}
+
+int lqmpc_rollout_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int T, const double *dA, const double *dB,
+                            const double *Q, const double *R, const double *P, const double *lb, const double *ub,
+                            const double *dx0, const double *A_true, const double *B_true, int true_per_instance,
+                            const double *x_ref, const double *u_ref, double *dJT, double *dX, double *dU,
+                            int32_t *dstatus, int32_t *diters)
+{
+    if (!h || !dA || !dB || !dx0 || !dJT || !A_true || !B_true) return fail(LQMPC_ERR_BAD_ARG, "NULL argument");
+    if (T < 1 || T > 100000) return fail(LQMPC_ERR_BAD_ARG, "T must be in [1,100000]");
+    Call c{nx, nu, N, T, 0, lqmpc::MODE_ROLLOUT, true_per_instance ? 1 : 0, Bsz, Q, R, P, lb, ub, x_ref, u_ref,
+           A_true, B_true, nullptr};
+    KParams p;
+    int rc = prepare(h, c, p);
+    if (rc) return rc;
+    p.A = dA; p.B = dB; p.x0 = dx0; p.JT = dJT; p.X = dX; p.U = dU; p.status = dstatus; p.iters = diters;
+    if (true_per_instance) { p.At = A_true; p.Bt = B_true; }
+    return launch(h, p);
+}
+
+int lqmpc_max_vn_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int K, const double *dA, const double *dB,
+                           const double *Q, const double *R, const double *P, const double *lb, const double *ub,
+                           const double *x0s, const double *x_ref, const double *u_ref, double *dMV, int32_t *dstatus,
+                           int32_t *diters)
+{
+    if (!h || !dA || !dB || !x0s || !dMV) return fail(LQMPC_ERR_BAD_ARG, "NULL argument");
+    if (K < 1 || K > 1024) return fail(LQMPC_ERR_BAD_ARG, "K must be in [1,1024]");
+    Call c{nx, nu, N, 0, K, lqmpc::MODE_MAXVN, 0, Bsz, Q, R, P, lb, ub, x_ref, u_ref, nullptr, nullptr, x0s};
+    KParams p;
+    int rc = prepare(h, c, p);
+    if (rc) return rc;
+    p.A = dA; p.B = dB; p.MV = dMV; p.status = dstatus; p.iters = diters;
+    return launch(h, p);
+}
+
+}  // extern "C"
+
+// ---- host-buffer flavours: stage in, run, stage out ----
+namespace {
+struct Stager {
+    lqmpc_handle *h;
+    int slot = 0;
+    int rc = 0;
+    template <typename T>
+    T *in(const T *host, size_t count)
+    {
+        if (rc || !host) return nullptr;
+        DevBuf &b = h->stage[slot++];
+        rc = ensure(h, b, count * sizeof(T));
+        if (rc) return nullptr;
+        hipError_t e = hipMemcpyAsync(b.p, host, count * sizeof(T), hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) { rc = fail(LQMPC_ERR_HIP, std::string("H2D: ") + hipGetErrorString(e)); return nullptr; }
+        return (T *)b.p;
+    }
+    template <typename T>
+    T *out(T *host, size_t count)
+    {
+        if (rc || !host) return nullptr;
+        DevBuf &b = h->stage[slot++];
+        rc = ensure(h, b, count * sizeof(T));
+        return rc ? nullptr : (T *)b.p;
+    }
+    template <typename T>
+    void back(T *host, const T *dev, size_t count)
+    {
+        if (rc || !host) return;
+        hipError_t e = hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, h->stream);
+        if (e != hipSuccess) rc = fail(LQMPC_ERR_HIP, std::string("D2H: ") + hipGetErrorString(e));
+    }
+};
+}  // namespace
+
+extern "C" {
+
+int lqmpc_solve_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, const double *A, const double *B,
+                      const double *Q, const double *R, const double *P, const double *lb, const double *ub,
+                      const double *x0, const double *x_ref, const double *u_ref, double *u0, double *VN,
+                      int32_t *status, int32_t *iters)
+{
+    if (!h || !A || !B || !x0 || !u0 || !VN) return fail(LQMPC_ERR_BAD_ARG, "NULL argument");
+    int rc = check_dims(nx, nu, N, Bsz);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    Stager s{h};
+    const size_t b = (size_t)Bsz;
+    const double *dA = s.in(A, b * nx * nx), *dB = s.in(B, b * nx * nu), *dx0 = s.in(x0, b * nx);
+    double *du0 = s.out(u0, b * nu), *dVN = s.out(VN, b);
+    int32_t *dst = s.out(status, b), *dit = s.out(iters, b);
+    if (s.rc) return s.rc;
+    rc = lqmpc_solve_batch_dev(h, nx, nu, N, Bsz, dA, dB, Q, R, P, lb, ub, dx0, x_ref, u_ref, du0, dVN, dst, dit);
+    if (rc) return rc;
+    s.back(u0, du0, b * nu); s.back(VN, dVN, b); s.back(status, dst, b); s.back(iters, dit, b);
+    if (s.rc) return s.rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int lqmpc_rollout_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int T, const double *A, const double *B,
+                        const double *Q, const double *R, const double *P, const double *lb, const double *ub,
+                        const double *x0, const double *A_true, const double *B_true, int true_per_instance,
+                        const double *x_ref, const double *u_ref, double *JT, double *X, double *U, int32_t *status,
+                        int32_t *iters)
+{
+    if (!h || !A || !B || !x0 || !JT || !A_true || !B_true) return fail(LQMPC_ERR_BAD_ARG, "NULL argument");
+    int rc = check_dims(nx, nu, N, Bsz);
+    if (rc) return rc;
+    if (T < 1 || T > 100000) return fail(LQMPC_ERR_BAD_ARG, "T must be in [1,100000]");
+    HIP_TRY(hipSetDevice(h->device));
+    Stager s{h};
+    const size_t b = (size_t)Bsz;
+    const double *dA = s.in(A, b * nx * nx), *dB = s.in(B, b * nx * nu), *dx0 = s.in(x0, b * nx);
+    const double *dAt = A_true, *dBt = B_true;
+    if (true_per_instance) { dAt = s.in(A_true, b * nx * nx); dBt = s.in(B_true, b * nx * nu); }
+    double *dJT = s.out(JT, b), *dX = s.out(X, b * nx * (T + 1)), *dU = s.out(U, b * nu * T);
+    int32_t *dst = s.out(status, b), *dit = s.out(iters, b);
+    if (s.rc) return s.rc;
+    rc = lqmpc_rollout_batch_dev(h, nx, nu, N, Bsz, T, dA, dB, Q, R, P, lb, ub, dx0, dAt, dBt, true_per_instance, x_ref,
+                                 u_ref, dJT, dX, dU, dst, dit);
+    if (rc) return rc;
+    s.back(JT, dJT, b); s.back(X, dX, b * nx * (T + 1)); s.back(U, dU, b * nu * T);
+    s.back(status, dst, b); s.back(iters, dit, b);
+    if (s.rc) return s.rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int lqmpc_max_vn_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int K, const double *A, const double *B,
+                       const double *Q, const double *R, const double *P, const double *lb, const double *ub,
+                       const double *x0s, const double *x_ref, const double *u_ref, double *MV, int32_t *status,
+                       int32_t *iters)
+{
+    if (!h || !A || !B || !x0s || !MV) return fail(LQMPC_ERR_BAD_ARG, "NULL argument");
+    int rc = check_dims(nx, nu, N, Bsz);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    Stager s{h};
+    const size_t b = (size_t)Bsz;
+    const double *dA = s.in(A, b * nx * nx), *dB = s.in(B, b * nx * nu);
+    double *dMV = s.out(MV, b);
+    int32_t *dst = s.out(status, b), *dit = s.out(iters, b);
+    if (s.rc) return s.rc;
+    rc = lqmpc_max_vn_batch_dev(h, nx, nu, N, Bsz, K, dA, dB, Q, R, P, lb, ub, x0s, x_ref, u_ref, dMV, dst, dit);
+    if (rc) return rc;
+    s.back(MV, dMV, b); s.back(status, dst, b); s.back(iters, dit, b);
+    if (s.rc) return s.rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int lqmpc_timer_begin(lqmpc_handle *h)
+{
+    if (!h) return fail(LQMPC_ERR_BAD_ARG, "handle is NULL");
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    return 0;
+}
+
+int lqmpc_timer_end(lqmpc_handle *h, float *ms)
+{
+    if (!h || !ms) return fail(LQMPC_ERR_BAD_ARG, "NULL argument");
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return 0;
+}
+
+}  // extern "C"

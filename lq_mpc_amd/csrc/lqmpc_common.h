@@ -1,0 +1,57 @@
+// lqmpc_common.h -- kernel parameter block and fp64 device helpers shared by the HIP kernels.
+// gfx950 (MI355X) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lqmpc {
+
+enum Mode : int { MODE_SOLVE = 0, MODE_ROLLOUT = 1, MODE_MAXVN = 2 };
+
+// Offsets (in doubles) into the small "shared" device block that holds the data common to the
+// whole batch: Q, R, P, lb, ub, x_ref (nx,N), u_ref (nu,N), A_true, B_true, x0s (nx,K).
+struct SharedOff {
+    int Q, R, P, lb, ub, xref, uref, At, Bt, x0s;
+};
+
+struct KParams {
+    int nx, nu, N, n;
+    int T, K, mode;
+    int true_per_instance;
+    int has_ref;
+    int max_iter, polish;
+    double eps, tau, z0_scale;
+    long long Bsz;
+    long long ws_stride;   // generic kernel: instances per workspace entry row
+    const double *A, *B, *x0, *At, *Bt;   // per-instance, instance-minor (device)
+    const double *sh;                     // shared block (device)
+    SharedOff so;
+    double *ws;                           // generic kernel workspace (device)
+    double *u0, *VN, *JT, *X, *U, *MV;    // outputs (device; X, U may be null)
+    int *status, *iters;                  // may be null
+};
+
+// ---- fp64 reciprocal / reciprocal square root: hardware seed + Newton steps ----
+// v_rcp_f64 / v_rsq_f64 give a seed good to ~2^-26 or better; two Newton steps reach ~1 ulp
+// without the div_scale/div_fmas/div_fixup sequence of an IEEE divide.  Arguments here are
+// always finite, positive and far from the denormal range (slacks, pivots).
+__device__ __forceinline__ double frcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+__device__ __forceinline__ double frsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    // y <- y + y*e*(1/2 + 3/8 e),  e = 1 - x y^2   (cubic step), then one quadratic step
+    double e = __builtin_fma(-x * y, y, 1.0);
+    y = __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
+    e = __builtin_fma(-x * y, y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+    return y;
+}
+
+}  // namespace lqmpc

@@ -1,0 +1,70 @@
+"""CPU: the C-ABI library loads and exports every symbol include/lqmpc.h declares; host logic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import lq_mpc_amd
+from lq_mpc_amd import _lib, box_from_Fu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "lqmpc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(lqmpc_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    assert sorted(_lib.EXPORTS) == declared
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_version_and_defaults():
+    L = _lib.lib()
+    assert b"gfx950" in L.lqmpc_version()
+    o = _lib.Options()
+    L.lqmpc_default_options(ctypes.byref(o))
+    assert o.eps == 1e-12 and o.max_iter == 50 and o.polish == 1 and o.kernel == _lib.KERNEL_AUTO
+    assert ctypes.sizeof(_lib.Options) == 40
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    L = _lib.lib()
+    if L.lqmpc_device_count() > 0:
+        pytest.skip("GPU present")
+    h = ctypes.c_void_p()
+    rc = L.lqmpc_create(0, ctypes.byref(h))
+    assert rc == -3 and not h.value and b"no HIP device" in L.lqmpc_last_error()
+    with pytest.raises(_lib.LqmpcError):
+        lq_mpc_amd.BatchSolver(0)
+
+
+def test_bad_handle_arguments():
+    L = _lib.lib()
+    assert L.lqmpc_sync(None) == -1
+    assert L.lqmpc_destroy(None) == 0
+    assert L.lqmpc_timer_begin(None) == -1
+
+
+def test_box_from_Fu():
+    lb, ub = box_from_Fu(np.vstack((10 * np.eye(2), -10 * np.eye(2))))      # working_example_multiple.py:25
+    np.testing.assert_allclose(lb, [-0.1, -0.1]); np.testing.assert_allclose(ub, [0.1, 0.1])
+    lb, ub = box_from_Fu(np.array([[4.0, 0], [0, 2.0], [-5.0, 0], [0, -1.0], [8.0, 0]]))
+    np.testing.assert_allclose(lb, [-0.2, -1.0]); np.testing.assert_allclose(ub, [0.125, 0.5])
+    with pytest.raises(ValueError):
+        box_from_Fu(np.array([[1.0, 1.0], [-1.0, 0.0]]))         # not a box row
+    with pytest.raises(ValueError):
+        box_from_Fu(np.array([[1.0, 0.0], [0.0, 1.0]]))          # unbounded below
+
+
+def test_product_path_does_not_import_oracle():
+    src_dir = os.path.join(ROOT, "lq_mpc_amd")
+    for dirpath, _, files in os.walk(src_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("# oracle", ""), f"{f} mentions the oracle"

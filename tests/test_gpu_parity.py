@@ -1,0 +1,202 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and the golden data.
+
+Tolerances (BASELINE.json north_star: "match ... to rtol 1e-5"):
+  V_N, J_T, M_V : relative error <= RTOL = 1e-5
+  u_0, U        : |u - u*| <= RTOL * max(|u*|, 1e-3 * u_max)   (late in a rollout u -> 0)
+The kernels normally land 6+ orders of magnitude inside these; TIGHT guards that margin.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from lq_mpc_amd import BatchSolver, LQ_MPC_Controller, LQ_MPC_Simulator, synth, KERNEL_GENERIC, KERNEL_AUTO
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+TIGHT = 1e-8
+U_MAX = 0.1
+
+A0 = np.array([[1.0, 0.7], [0.12, 0.4]])
+B0 = np.array([[1.0], [1.2]])
+Q2 = 2.0 * np.eye(2)
+R1 = np.eye(1)
+F_U = np.vstack((10 * np.eye(1), -10 * np.eye(1)))
+X_START = np.array([0.15916231240837822, 0.15916231240837819])
+
+
+def rel(a, b):
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))
+
+
+def u_err(u, ur, umax=U_MAX):
+    return np.max(np.abs(u - ur) / np.maximum(np.abs(ur), 1e-3 * umax))
+
+
+def args(b):
+    return (b["N"], b["A"], b["B"], b["Q"], b["R"], b["P"], b["lb"], b["ub"])
+
+
+KERNELS = [KERNEL_GENERIC, KERNEL_AUTO]
+
+
+@pytest.fixture(params=KERNELS, ids=["generic", "auto"])
+def ksolver(request, solver):
+    solver.set_options(kernel=request.param)
+    yield solver
+    solver.set_options(kernel=KERNEL_AUTO)
+
+
+# ---------------- seeded synthetic configs vs the oracle ----------------
+@pytest.mark.parametrize("cfg,bsz", [(1, 1), (2, 512), (3, 512), (4, 128), (5, 64)])
+def test_solve_batch_vs_oracle(ksolver, cfg, bsz, golden_dir):
+    b = synth.make_batch(cfg, Bsz=bsz, fixture_dir=golden_dir)
+    got = ksolver.solve_batch(*args(b), b["x0"])
+    ref = orc.solve_batch(*args(b), b["x0"])
+    assert np.all(got["status"] == 0)
+    assert rel(got["V_N"], ref["V_N"]) < RTOL and u_err(got["u_0"], ref["u_0"]) < RTOL
+    assert rel(got["V_N"], ref["V_N"]) < TIGHT and u_err(got["u_0"], ref["u_0"]) < 1e-6
+
+
+@pytest.mark.parametrize("cfg,bsz,T", [(1, 1, 50), (2, 512, 30), (3, 512, 30), (4, 64, 10), (5, 64, 4)])
+def test_rollout_batch_vs_oracle(ksolver, cfg, bsz, T, golden_dir):
+    b = synth.make_batch(cfg, Bsz=bsz, fixture_dir=golden_dir)
+    got = ksolver.rollout_batch(T, *args(b), b["x0"], b["A_true"], b["B_true"], want_traj=True)
+    ref = orc.rollout_batch(T, *args(b), b["x0"], b["A_true"], b["B_true"], want_traj=True)
+    assert np.all(got["status"] == 0)
+    assert rel(got["J_T"], ref["J_T"]) < RTOL and rel(got["J_T"], ref["J_T"]) < TIGHT
+    assert u_err(got["U"], ref["U"]) < RTOL
+    scale = np.max(np.abs(ref["X"]))
+    assert np.max(np.abs(got["X"] - ref["X"])) < RTOL * scale
+    assert np.all(got["iters"] > 0)
+
+
+@pytest.mark.parametrize("cfg,bsz", [(2, 256), (3, 128)])
+def test_max_vn_batch_vs_oracle(ksolver, cfg, bsz, golden_dir):
+    b = synth.make_batch(cfg, Bsz=bsz, fixture_dir=golden_dir)
+    rng = np.random.default_rng(5)
+    x0s = rng.standard_normal((b["nx"], 8)) * 0.3
+    got = ksolver.max_vn_batch(*args(b), x0s)
+    ref = orc.max_vn_batch(*args(b), x0s)
+    assert np.all(got["status"] == 0) and rel(got["M_V"], ref) < TIGHT
+
+
+# ---------------- the reference's own fixture data through the GPU path ----------------
+def test_golden_true_cost_tables(ksolver, golden_dir):
+    """error_{A,B}_f.npy -> true_cost_error / true_cost_horizon of the reference's npz (utils_class.py:802-833, 886-916)."""
+    d = np.load(os.path.join(golden_dir, "data_lq_mpc_multipleSys.npz"))
+    eA = np.load(os.path.join(golden_dir, "error_A_f.npy"))
+    eB = np.load(os.path.join(golden_dir, "error_B_f.npy"))
+    lb, ub = np.array([-0.1]), np.array([0.1])
+    A = (A0[:, :, None, None] + eA).reshape(2, 2, 1000)      # the file layout IS the SoA layout
+    B = (B0[:, :, None, None] + eB).reshape(2, 1, 1000)
+    x0 = np.repeat(X_START[:, None], 1000, 1)
+    J = ksolver.rollout_batch(30, 7, A, B, Q2, R1, Q2, lb, ub, x0, A0, B0)["J_T"].reshape(100, 10)
+    assert rel(J, d["true_cost_error"]) < RTOL and rel(J, d["true_cost_error"]) < 1e-10
+    for k, N in enumerate(range(6, 11)):
+        A4, B4 = A0[:, :, None] + eA[:, :, :, 4], B0[:, :, None] + eB[:, :, :, 4]
+        J = ksolver.rollout_batch(30, N, A4, B4, Q2, R1, Q2, lb, ub, x0[:, :100], A0, B0)["J_T"]
+        assert rel(J, d["true_cost_horizon"][:, k]) < 1e-10
+    V = ksolver.solve_batch(30, A0[:, :, None], B0[:, :, None], Q2, R1, Q2, lb, ub, X_START[:, None])["V_N"][0]
+    assert abs(V - float(d["V_expert"])) / float(d["V_expert"]) < 1e-10
+
+
+def test_dropin_classes_reproduce_reference_scripts(solver):
+    """mpc_test.py:33-66 and working_example_single.py:62-66 with the reference's class API."""
+    x0 = np.array([0.1125, 0.19])
+    mpc = LQ_MPC_Controller(20, A0, B0, Q2, R1, Q2, F_U)
+    info = mpc.solve(x0, np.zeros((2, 20)), np.zeros((1, 20)))
+    assert set(info) == {"u_0", "V_N"} and info["u_0"].shape == (1,) and isinstance(info["V_N"], float)
+    assert abs(info["V_N"] - 0.17375571642447996) < 1e-10 and abs(info["u_0"][0] + 0.1) < 1e-9
+    sim = LQ_MPC_Simulator(20, 6, A0, B0, Q2, R1, Q2, F_U)
+    tr = sim.simulate(x0, np.array([[1.01, 0.7], [0.12, 0.41]]), np.array([[1.0], [1.21]]), np.zeros((2, 6)), np.zeros((1, 6)))
+    assert set(tr) == {"X", "U", "J_T"} and tr["X"].shape == (2, 21) and tr["U"].shape == (1, 20)
+    assert abs(tr["J_T"] - 0.17571889572646185) < 1e-10
+    np.testing.assert_allclose(tr["X"][:, 0], x0)
+    ref = orc.simulate(20, 6, A0, B0, Q2, R1, Q2, [-0.1], [0.1], x0, np.array([[1.01, 0.7], [0.12, 0.41]]), np.array([[1.0], [1.21]]))
+    assert np.max(np.abs(tr["X"] - ref["X"])) < 1e-9 and np.max(np.abs(tr["U"] - ref["U"])) < 1e-9
+    x0_vec = orc.circle_generator(8, 1.5, 0.04503580745099056, Q2)
+    mv = max(LQ_MPC_Controller(6, A0, B0, Q2, R1, Q2, F_U).solve(x0_vec[:, k], np.zeros((2, 6)), np.zeros((1, 6)))["V_N"] for k in range(8))
+    assert abs(mv - 0.2022946791688417) < 1e-10
+
+
+# ---------------- edge cases ----------------
+def test_zero_state_and_saturated_cases(ksolver):
+    b = synth.make_batch(3, Bsz=64)
+    x0 = b["x0"].copy()
+    x0[:, :16] = 0.0                      # exactly at the origin: u = 0, V = 0
+    x0[:, 16:32] *= 50.0                  # far outside: every early input saturated
+    x0[:, 32:48] *= 1e-6                  # tiny: unconstrained, u linear in x0
+    got = ksolver.solve_batch(*args(b), x0)
+    ref = orc.solve_batch(*args(b), x0)
+    assert np.all(got["status"] == 0)
+    assert np.all(got["u_0"][:, :16] == 0) and np.all(np.abs(got["V_N"][:16]) < 1e-300)
+    assert np.all(np.abs(np.abs(got["u_0"][:, 16:32]).max(0) - U_MAX) < 1e-12)
+    assert u_err(got["u_0"][:, 16:], ref["u_0"][:, 16:]) < RTOL
+    assert rel(got["V_N"][16:], ref["V_N"][16:]) < TIGHT
+    np.testing.assert_allclose(got["u_0"][:, 32:48], ref["u_0"][:, 32:48], rtol=1e-9)
+
+
+def test_references_terminal_weight_asymmetric_box_and_per_instance_plant(ksolver):
+    rng = np.random.default_rng(3)
+    nx, nu, N, Bsz, T = 3, 2, 6, 96, 8
+    A = np.ascontiguousarray(0.7 * rng.standard_normal((nx, nx, 1)) + 0.05 * rng.standard_normal((nx, nx, Bsz)))
+    B = np.ascontiguousarray(rng.standard_normal((nx, nu, 1)) + 0.05 * rng.standard_normal((nx, nu, Bsz)))
+    Q, R, P = np.diag([2.0, 1.0, 3.0]), np.array([[1.0, 0.2], [0.2, 0.5]]), np.diag([5.0, 4.0, 1.0])
+    lb, ub = np.array([-0.3, -0.05]), np.array([0.1, 0.4])
+    x0 = rng.standard_normal((nx, Bsz))
+    xr, ur = 0.3 * rng.standard_normal((nx, N)), 0.1 * rng.standard_normal((nu, N))
+    At = np.ascontiguousarray(A + 0.01 * rng.standard_normal((nx, nx, Bsz)))
+    Bt = np.ascontiguousarray(B + 0.01 * rng.standard_normal((nx, nu, Bsz)))
+    got = ksolver.solve_batch(N, A, B, Q, R, P, lb, ub, x0, xr, ur)
+    ref = orc.solve_batch(N, A, B, Q, R, P, lb, ub, x0, xr, ur)
+    assert np.all(got["status"] == 0)
+    assert rel(got["V_N"], ref["V_N"]) < TIGHT and u_err(got["u_0"], ref["u_0"], 0.1) < RTOL
+    g2 = ksolver.rollout_batch(T, N, A, B, Q, R, P, lb, ub, x0, At, Bt, xr, ur, want_traj=True)
+    r2 = orc.rollout_batch(T, N, A, B, Q, R, P, lb, ub, x0, At, Bt, xr, ur, want_traj=True)
+    assert rel(g2["J_T"], r2["J_T"]) < TIGHT and u_err(g2["U"], r2["U"], 0.1) < RTOL
+
+
+def test_ragged_batch_sizes(ksolver):
+    """Batches that do not fill a wavefront / workgroup, including a single instance."""
+    for bsz in (1, 3, 63, 65, 257):
+        b = synth.make_batch(3, Bsz=bsz)
+        got = ksolver.rollout_batch(5, *args(b), b["x0"], b["A_true"], b["B_true"])
+        ref = orc.rollout_batch(5, *args(b), b["x0"], b["A_true"], b["B_true"])
+        assert got["J_T"].shape == (bsz,) and rel(got["J_T"], ref["J_T"]) < TIGHT
+
+
+def test_bad_arguments_are_reported(solver):
+    b = synth.make_batch(2, Bsz=8)
+    with pytest.raises(Exception):
+        solver.solve_batch(b["N"], b["A"], b["B"], b["Q"], b["R"], b["P"], b["ub"], b["lb"], b["x0"])   # empty box
+    with pytest.raises(Exception):
+        solver.rollout_batch(0, *args(b), b["x0"], b["A_true"], b["B_true"])                            # T = 0
+    with pytest.raises(ValueError):
+        LQ_MPC_Controller(5, A0, B0, Q2, R1, Q2, np.array([[1.0], [2.0]]))                               # one-sided
+
+
+# ---------------- size-independent properties at BASELINE.json's full sizes ----------------
+@pytest.mark.parametrize("cfg", [2, 3])
+def test_full_size_properties(solver, cfg, golden_dir):
+    """Odd symmetry (zero refs, symmetric box): solve(-x0) = (-u_0, V_N); bounds respected; x0 -> 0 gives the
+    unconstrained linear law; a 1024-instance sample agrees with the oracle."""
+    b = synth.make_batch(cfg, fixture_dir=golden_dir)
+    assert b["Bsz"] == synth.CONFIGS[cfg]["Bsz"]
+    g1 = solver.solve_batch(*args(b), b["x0"])
+    g2 = solver.solve_batch(*args(b), -b["x0"])
+    assert np.all(g1["status"] == 0) and np.all(g2["status"] == 0)
+    assert np.max(np.abs(g1["u_0"] + g2["u_0"])) < 1e-9 and rel(g1["V_N"], g2["V_N"]) < 1e-10
+    assert np.all(np.abs(g1["u_0"]) <= U_MAX + 1e-15)
+    s1 = solver.solve_batch(*args(b), 1e-4 * b["x0"])
+    s2 = solver.solve_batch(*args(b), 2e-4 * b["x0"])
+    assert np.max(np.abs(2 * s1["u_0"] - s2["u_0"])) < 1e-12 and rel(4 * s1["V_N"], s2["V_N"]) < 1e-9
+    idx = np.random.default_rng(0).choice(b["Bsz"], 1024, replace=False)
+    sub = dict(b, A=np.ascontiguousarray(b["A"][:, :, idx]), B=np.ascontiguousarray(b["B"][:, :, idx]))
+    ref = orc.solve_batch(*args(sub), np.ascontiguousarray(b["x0"][:, idx]))
+    assert rel(g1["V_N"][idx], ref["V_N"]) < TIGHT and u_err(g1["u_0"][:, idx], ref["u_0"]) < RTOL
+    r1 = solver.rollout_batch(30, *args(b), b["x0"], b["A_true"], b["B_true"])
+    rr = orc.rollout_batch(30, *args(sub), np.ascontiguousarray(b["x0"][:, idx]), b["A_true"], b["B_true"])
+    assert np.all(r1["status"] == 0) and rel(r1["J_T"][idx], rr["J_T"]) < TIGHT
