@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC QP-steps/sec on BASELINE.json's headline config, one process per GPU.
+
+A "step" is one pass of the hot path over one batch: one closed-loop rollout launch
+(LQ_MPC_Simulator.simulate semantics, /root/reference/utils_class.py:245-285) over
+Bsz = 65536 synthetic 4-state/2-input systems with horizon N = 10 and T = 30 MPC steps, i.e.
+65536 x 30 condensed box-QP solves per GPU per step, inputs already resident in HBM.  With
+--gpus N (launched by torch.distributed.run, one rank per GPU) every rank owns its own shard of
+systems (weak scaling, no data-path collective) and the per-system closed-loop costs J_T are
+all-gathered over RCCL at the end of every step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+HIP-event timed on the launch stream) and `cpu_baseline` (the CPU oracle on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = FP64 matrix peak (not in the microarch guide)
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def f_iter(n):
+    """Algorithmic flops of one interior-point iteration: n^3/3 + 6 n^2."""
+    return n ** 3 / 3.0 + 6.0 * n * n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=3, help="SURVEY 8(d) config id (3 = headline)")
+    ap.add_argument("--bsz", type=int, default=0, help="systems per GPU (default: the config's)")
+    ap.add_argument("--T", type=int, default=0, help="rollout length (default: the config's, 30)")
+    ap.add_argument("--mode", choices=["rollout", "oneshot"], default="rollout")
+    ap.add_argument("--kernel", choices=["auto", "generic", "specialized"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-oneshot", action="store_true", help="skip the extra one-shot measurement")
+    args = ap.parse_args()
+
+    import torch
+    from lq_mpc_amd import BatchSolver, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = synth.CONFIGS[args.config]
+    nx, nu, N = cfg["nx"], cfg["nu"], cfg["N"]
+    n = N * nu
+    Bsz = args.bsz or cfg["Bsz"]
+    T = args.T or cfg["T"]
+    # every rank owns a different shard of the (conceptually world*Bsz) batch: reseed per rank
+    b = synth.make_batch(args.config, Bsz=Bsz, fixture_dir=os.path.join(ROOT, "tests", "golden"))
+    if world > 1:
+        rng = np.random.default_rng(977 + rank)
+        perm = rng.permutation(Bsz)
+        scale = rng.uniform(0.8, 1.25, Bsz)
+        b["A"] = np.ascontiguousarray(b["A"][:, :, perm]); b["B"] = np.ascontiguousarray(b["B"][:, :, perm])
+        b["x0"] = np.ascontiguousarray(b["x0"][:, perm] * scale)
+
+    dA = torch.from_numpy(b["A"]).to(dev); dB = torch.from_numpy(b["B"]).to(dev); dx0 = torch.from_numpy(b["x0"]).to(dev)
+    dJT = torch.empty(Bsz, dtype=torch.float64, device=dev)
+    du0 = torch.empty((nu, Bsz), dtype=torch.float64, device=dev)
+    dVN = torch.empty(Bsz, dtype=torch.float64, device=dev)
+    dst = torch.empty(Bsz, dtype=torch.int32, device=dev)
+    dit = torch.empty(Bsz, dtype=torch.int32, device=dev)
+    gathered = torch.empty(world * Bsz, dtype=torch.float64, device=dev) if world > 1 else None
+
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    kern = {"auto": 0, "generic": 1, "specialized": 2}[args.kernel]
+    s = BatchSolver(local_rank, stream=stream, kernel=kern)
+    s.reserve(nx, nu, N, Bsz, T)
+
+    def launch_rollout():
+        s.rollout_batch_dev(nx, nu, N, Bsz, T, dA, dB, b["Q"], b["R"], b["P"], b["lb"], b["ub"], dx0,
+                            b["A_true"], b["B_true"], dJT, dstatus=dst, diters=dit)
+
+    def launch_oneshot():
+        s.solve_batch_dev(nx, nu, N, Bsz, dA, dB, b["Q"], b["R"], b["P"], b["lb"], b["ub"], dx0, du0, dVN,
+                          dstatus=dst, diters=dit)
+
+    def run(launch, steps, warmup, qp_per_launch):
+        def one_step(ev=None):
+            if ev is not None:
+                ev[0].record()
+            launch()
+            if ev is not None:
+                ev[1].record()
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, dJT)
+        for _ in range(warmup):
+            one_step()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one_step(evs[i])
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        kernel_ms = float(np.mean([a.elapsed_time(bb) for a, bb in evs]))
+        return dt, kernel_ms, world * qp_per_launch * steps / dt
+
+    launch = launch_rollout if args.mode == "rollout" else launch_oneshot
+    qp_per_launch = Bsz * (T if args.mode == "rollout" else 1)
+    dt, kernel_ms, value = run(launch, args.steps, args.warmup, qp_per_launch)
+    kernel_name = s.last_kernel()
+    status_bad = int((dst != 0).sum().item())
+    iters_total = float(dit.double().sum().item())
+    iters_mean = iters_total / qp_per_launch
+    if world > 1:
+        agg = torch.tensor([iters_total, float(status_bad)], dtype=torch.float64, device=dev)
+        dist.all_reduce(agg)
+        iters_mean = float(agg[0].item()) / (world * qp_per_launch)
+        status_bad = int(agg[1].item())
+
+    # ---- roofline of the dominant kernel (the one launch per step), per launch ----
+    cond_flops = (N * nx * n * n + 2 * N * nx * nx * nu)            # condensing, once per instance
+    f_step = iters_mean * f_iter(n) + 2 * n * nx + cond_flops / (T if args.mode == "rollout" else 1)
+    alg_bytes = 8 * (nx * nx + nx * nu + nx + (1 if args.mode == "rollout" else nu + 1))   # per instance per launch
+    flops_launch = f_step * qp_per_launch
+    bytes_launch = alg_bytes * Bsz
+    tflops = flops_launch / (kernel_ms * 1e-3) / 1e12
+    gbs = bytes_launch / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tf):
+        try:
+            rec = json.load(open(tf)).get(f"{kernel_name}:{args.mode}:C{args.config}:Bsz{Bsz}:T{T}")
+            traffic = rec["hbm_bytes_per_launch"] if rec else None
+        except Exception:
+            traffic = None
+    roofline = {
+        "kernel": kernel_name, "bound": "fp64_valu", "achieved": round(tflops, 4), "peak": FP64_PEAK_TFLOPS,
+        "unit": "TFLOP/s", "frac": round(tflops / FP64_PEAK_TFLOPS, 5), "traffic": traffic,
+        "kernel_ms_per_launch": round(kernel_ms, 4), "iters_mean": round(iters_mean, 3),
+        "flops_per_qp_step": round(f_step, 1), "alg_bytes_per_instance": alg_bytes,
+        "hbm": {"achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 7)},
+        "note": "FP64 vector ALU binds (SURVEY 8(d)): ~250 B of unique HBM traffic vs ~40 kflop per QP-step; "
+                "flops = iters_mean*(n^3/3+6n^2)+2*n*nx+condensing/T, polish solve not counted",
+    }
+
+    extra = {}
+    if args.mode == "rollout" and not args.no_oneshot:
+        dt1, kms1, v1 = run(launch_oneshot, max(args.steps, 20), 3, Bsz)
+        it1 = float(dit.double().sum().item()) / Bsz
+        extra["oneshot"] = {"value": round(v1, 1), "unit": "QP-steps/s", "kernel_ms_per_launch": round(kms1, 4),
+                            "iters_mean": round(it1, 3), "qp_per_launch": Bsz}
+
+    # ---- CPU baseline: the oracle (port), all host cores, bounded sample, rank 0 at N=1 only ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        cores = len(os.sched_getaffinity(0))
+        def cpu_run(m):
+            A = np.ascontiguousarray(b["A"][:, :, :m]); Bm = np.ascontiguousarray(b["B"][:, :, :m])
+            x0 = np.ascontiguousarray(b["x0"][:, :m])
+            t = time.perf_counter()
+            if args.mode == "rollout":
+                orc.rollout_batch(T, N, A, Bm, b["Q"], b["R"], b["P"], b["lb"], b["ub"], x0, b["A_true"], b["B_true"], threads=cores)
+                q = m * T
+            else:
+                orc.solve_batch(N, A, Bm, b["Q"], b["R"], b["P"], b["lb"], b["ub"], x0, threads=cores)
+                q = m
+            return q, time.perf_counter() - t
+        m0 = min(Bsz, 256)
+        q0, t0 = cpu_run(m0)
+        m = int(min(Bsz, max(m0, m0 * 12.0 / max(t0, 1e-3))))      # aim at ~12 s of CPU work
+        q, t = cpu_run(m)
+        cpu = {"value": round(q / t, 1), "unit": "QP-steps/s", "cores": cores, "kind": "port",
+               "sample": f"first {m} instances of the same batch ({q} QP-steps, {t:.1f} s), exact active-set oracle, "
+                         f"OpenMP over instances"}
+
+    if rank == 0:
+        out = {
+            "metric": "MPC QP-steps/sec (batched systems) at n_x=4,n_u=2,N=10; 1/2/4/8 GPU",
+            "value": round(value, 1), "unit": "QP-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C{args.config}: {Bsz} systems/GPU, n_x={nx}, n_u={nu}, N={N}, box |u|<=0.1, "
+                                   + (f"closed-loop rollout T={T} (one launch = {Bsz}x{T} QP-steps)" if args.mode == "rollout"
+                                      else "one-shot open-loop solve (one launch = one QP per system)"),
+                       "mode": args.mode, "batch_per_gpu": Bsz, "T": T if args.mode == "rollout" else 1,
+                       "parallelism": f"dp{world} (independent shards, RCCL all-gather of J_T per step)" if world > 1 else "dp1",
+                       "options": s.get_options(), "status_nonzero": status_bad},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        out.update(extra)
+        print(json.dumps(out))
+    s.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
