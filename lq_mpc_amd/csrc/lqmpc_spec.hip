@@ -1,6 +1,812 @@
-// lqmpc_spec.hip -- register-resident specialisations (stub; filled in below in a later commit)
+// lqmpc_spec.hip -- register-resident, sub-wavefront-cooperative kernels for the BASELINE configs.
+//
+// Mapping (gfx950, wave64, one wave per 64-thread workgroup, one wave per SIMD):
+//   LPS lanes cooperate on one (A,B) instance ("group"); a wave holds 64/LPS instances.
+//   Row i of the condensed n x n system belongs to lane r = i % LPS of its group, as row-block
+//   jb = i / LPS.  Each lane keeps ITS rows of P = 2(Gamma'Qbar Gamma + Rbar), of the working
+//   matrix K -> L (in-place Cholesky), of Fq = 2 Gamma'Qbar Phi and its slice of every
+//   interior-point vector in VGPRs; all loops are fully unrolled so every register index is a
+//   compile-time constant.  Cross-lane traffic inside a group is DPP quad_perm moves (two
+//   v_mov_b32_dpp per double); nothing is spilled to HBM.  The only LDS use is a transposed,
+//   bank-conflict-free mirror of L (for the column-oriented backward substitution) and the
+//   staging of A^k B during condensing.
+//
+// Per-instance HBM traffic is exactly the algorithmic bytes: A, B, x0 in, results out.
+//
+// Restates /root/reference/utils_class.py:48-91 (solve) and 245-285 (simulate); the
+// interior-point method replaces cvxpy's QP back-end (utils_class.py:84-88).
 #include "lqmpc_common.h"
+
 namespace lqmpc {
-bool spec_available(int, int, int) { return false; }
-bool launch_spec(const KParams &, hipStream_t, const char **) { return false; }
+
+// ---------------- cross-lane primitives inside a group of LPS lanes ----------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    // every source lane of a quad_perm is valid, so the destination's old value is never kept:
+    // mov_dpp (old = undef) lets the compiler read the source register in place (no copy, no s_nop)
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_mov_u32(unsigned x)
+{
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)x, CTRL, 0xF, 0xF, true);
+}
+
+// value of sub-lane SRC of my group, in every lane of the group
+template <int LPS, int SRC>
+__device__ __forceinline__ double bcast(double x)
+{
+    static_assert(LPS == 1 || LPS == 2 || LPS == 4, "quad_perm covers groups of 1, 2, 4 lanes");
+    if constexpr (LPS == 1) return x;
+    else if constexpr (LPS == 2) return dpp_mov<(SRC == 0) ? 0xA0 : 0xF5>(x);   // [0,0,2,2] / [1,1,3,3]
+    else return dpp_mov<SRC * 0x55>(x);                                          // [s,s,s,s]
+}
+
+template <int LPS>
+__device__ __forceinline__ double group_sum(double x)
+{
+    if constexpr (LPS >= 2) x += dpp_mov<0xB1>(x);   // [1,0,3,2]
+    if constexpr (LPS >= 4) x += dpp_mov<0x4E>(x);   // [2,3,0,1]
+    return x;
+}
+template <int LPS>
+__device__ __forceinline__ double group_max(double x)
+{
+    if constexpr (LPS >= 2) x = fmax(x, dpp_mov<0xB1>(x));
+    if constexpr (LPS >= 4) x = fmax(x, dpp_mov<0x4E>(x));
+    return x;
+}
+template <int LPS>
+__device__ __forceinline__ unsigned group_or(unsigned x)
+{
+    if constexpr (LPS >= 2) x |= dpp_mov_u32<0xB1>(x);
+    if constexpr (LPS >= 4) x |= dpp_mov_u32<0x4E>(x);
+    return x;
+}
+template <int LPS>
+__device__ __forceinline__ unsigned group_and(unsigned x)
+{
+    if constexpr (LPS >= 2) x &= dpp_mov_u32<0xB1>(x);
+    if constexpr (LPS >= 4) x &= dpp_mov_u32<0x4E>(x);
+    return x;
+}
+
+// ---------------- the kernel, specialised on the problem shape ----------------
+template <int NX, int NU, int N, int LPS>
+struct Spec {
+    static constexpr int n = N * NU;
+    static_assert(n % LPS == 0, "n must be a multiple of the group width");
+    static_assert(LPS == 1 || LPS % NU == 0, "group width must be a multiple of nu");
+    static_assert(n <= 32, "active-set bit mask is 32 bits wide");
+    static constexpr int RB = n / LPS;              // rows per lane
+    static constexpr int SPW = 64 / LPS;            // instances per wave
+    static constexpr int TRI = LPS * RB * (RB + 1) / 2;
+    __host__ __device__ static constexpr int off(int jb) { return LPS * jb * (jb + 1) / 2; }
+    __host__ __device__ static constexpr int rowlen(int jb) { return (jb + 1) * LPS; }
+    // LDS mirror of L, column-major: column c holds row-blocks jb >= c/LPS, each 64 doubles
+    // ([instance][sub-lane]); column starts are skewed by c doubles so that the backward
+    // substitution's reads (4 lanes of a group in 4 different columns) hit distinct banks.
+    __host__ __device__ static constexpr int colstart(int c)
+    {
+        int s = 0;
+        for (int cc = 0; cc < c; ++cc) s += (RB - cc / LPS) * 64;
+        return s + c;
+    }
+    static constexpr int MIRROR = (LPS == 1) ? 0 : colstart(n);
+    static constexpr int STAGE = (LPS == 1) ? 0 : N * NX * NU * SPW;
+    static constexpr int LDS_DOUBLES = MIRROR > STAGE ? MIRROR : (STAGE > 0 ? STAGE : 1);
+
+    // ---- per-lane state (all in VGPRs) ----
+    double Pm[TRI];        // own rows of P, row-block jb padded to rowlen(jb) columns
+    double a[TRI];         // K, then L; diagonal blocks are zero on and above the diagonal after chol()
+    double invd[RB];       // 1 / l_ii of own rows
+    double Fq[RB][NX];     // own rows of 2 Gamma' Qbar Phi
+    double qr[RB];         // own rows of the constant part of q (references, box centre)
+    double v[RB], sl[RB], su[RB], zl[RB], zu[RB], rd[RB];
+    double x[NX];          // current state (replicated in the group)
+    double hown, cown;     // half-width / centre of own rows' input (LPS > 1: same input for all own rows)
+    int r, s;              // sub-lane in group, group in wave
+    double *lds;
+
+    // half-width and centre of own row jb
+    __device__ __forceinline__ double hh(const KParams &p, int jb) const
+    {
+        if constexpr (LPS == 1) { const int k = jb % NU; return 0.5 * (p.sh[p.so.ub + k] - p.sh[p.so.lb + k]); }
+        else return hown;
+    }
+    __device__ __forceinline__ double cc(const KParams &p, int jb) const
+    {
+        if constexpr (LPS == 1) { const int k = jb % NU; return 0.5 * (p.sh[p.so.ub + k] + p.sh[p.so.lb + k]); }
+        else return cown;
+    }
+
+    // ---- in-place Cholesky of the row-distributed matrix in a[] (right-looking, column k) ----
+    // On exit: strict lower part = L, invd = 1/diag(L), diagonal blocks zero on/above the
+    // diagonal, and (LPS > 1) L mirrored into LDS column-major.  Returns false on a bad pivot.
+    __device__ __forceinline__ bool chol()
+    {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+            const int kb = k / LPS, kr = k % LPS;
+            double d = a[off(kb) + k];
+            d = bcast_rt(d, kr);
+            ok = ok && (d > 0.0);
+            const double inv = frsqrt(d);
+            if (LPS == 1 || r == kr) invd[kb] = inv;
+            // scale column k: rows below the diagonal; zero the diagonal block on/above it
+            if constexpr (LPS == 1) a[off(kb) + k] = 0.0;
+            else a[off(kb) + k] = (r > kr) ? a[off(kb) + k] * inv : 0.0;
+#pragma unroll
+            for (int jb = kb + 1; jb < RB; ++jb) a[off(jb) + k] *= inv;
+            if constexpr (LPS > 1) {
+#pragma unroll
+                for (int jb = kb; jb < RB; ++jb) lds[colstart(k) + ((jb - kb) * SPW + s) * LPS + r] = a[off(jb) + k];
+            }
+            // trailing update: a[i][c] -= l_ik * l_ck for c > k, rows i >= c
+#pragma unroll
+            for (int c = k + 1; c < n; ++c) {
+                const int cb = c / LPS, cr = c % LPS;
+                const double lck = bcast_rt(a[off(cb) + k], cr);
+#pragma unroll
+                for (int jb = cb; jb < RB; ++jb) a[off(jb) + c] = __builtin_fma(-a[off(jb) + k], lck, a[off(jb) + c]);
+            }
+        }
+        return ok;
+    }
+
+    // bcast with a source known at compile time after unrolling (switch folds away)
+    __device__ __forceinline__ double bcast_rt(double xv, int src) const
+    {
+        if constexpr (LPS == 1) return xv;
+        else if constexpr (LPS == 2) return src == 0 ? bcast<2, 0>(xv) : bcast<2, 1>(xv);
+        else {
+            switch (src) {
+            case 0: return bcast<4, 0>(xv);
+            case 1: return bcast<4, 1>(xv);
+            case 2: return bcast<4, 2>(xv);
+            default: return bcast<4, 3>(xv);
+            }
+        }
+    }
+
+    // ---- solve (L L') y = b in place, b row-distributed ----
+    __device__ __forceinline__ void solve(double (&b)[RB])
+    {
+        // forward, column-oriented: after step k every row i > k has b_i -= l_ik y_k.
+        // b keeps the un-scaled residuals; y_i = b_i * invd_i is applied at the end.
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+            const int kb = k / LPS, kr = k % LPS;
+            const double yk = bcast_rt(b[kb] * invd[kb], kr);
+#pragma unroll
+            for (int jb = kb; jb < RB; ++jb) {
+                if (LPS == 1 && jb == kb) continue;   // its own row
+                b[jb] = __builtin_fma(-a[off(jb) + k], yk, b[jb]);   // diagonal block: zeros for rows <= k
+            }
+        }
+#pragma unroll
+        for (int jb = 0; jb < RB; ++jb) b[jb] *= invd[jb];
+        // backward, column-oriented: after step k every row i < k has y_i -= l_ki x_k
+#pragma unroll
+        for (int k = n - 1; k >= 0; --k) {
+            const int kb = k / LPS, kr = k % LPS;
+            const double xk = bcast_rt(b[kb] * invd[kb], kr);
+#pragma unroll
+            for (int jb = 0; jb <= kb; ++jb) {
+                if constexpr (LPS == 1) {
+                    if (jb == kb) continue;
+                    b[jb] = __builtin_fma(-a[off(kb) + jb], xk, b[jb]);       // l_{k,jb} from my own row k
+                } else {
+                    // l_{k,i} for my column i = jb*LPS + r: mirror column i, row k
+                    // = colstart(jb*LPS + r) + ((kb - jb)*SPW + s)*LPS + kr   (zero when i >= k)
+                    const double lki = lds[colstart_r(jb) + ((kb - jb) * SPW + s) * LPS + kr];
+                    b[jb] = __builtin_fma(-lki, xk, b[jb]);
+                }
+            }
+        }
+#pragma unroll
+        for (int jb = 0; jb < RB; ++jb) b[jb] *= invd[jb];
+    }
+
+    // colstart(jb*LPS + r) for the run-time sub-lane r: the per-column sizes are equal inside a
+    // row-block, so it is colstart(jb*LPS) + r * ((RB - jb)*64 + 1)
+    __device__ __forceinline__ int colstart_r(int jb) const { return colstart(jb * LPS) + r * ((RB - jb) * 64 + 1); }
+
+    // ---- q = Fq x + qr for own rows ----
+    __device__ __forceinline__ void linear_term(double (&q)[RB]) const
+    {
+#pragma unroll
+        for (int jb = 0; jb < RB; ++jb) {
+            double t = qr[jb];
+#pragma unroll
+            for (int aa = 0; aa < NX; ++aa) t = __builtin_fma(Fq[jb][aa], x[aa], t);
+            q[jb] = t;
+        }
+    }
+
+    // ---- y = P w for a row-distributed w (symmetric product from the stored lower part) ----
+    __device__ __forceinline__ void symv(const double (&w)[RB], double (&y)[RB]) const
+    {
+        double wall[n], t[n];
+#pragma unroll
+        for (int j = 0; j < n; ++j) { wall[j] = bcast_rt(w[j / LPS], j % LPS); t[j] = 0.0; }
+#pragma unroll
+        for (int jb = 0; jb < RB; ++jb) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < rowlen(jb); ++j) {
+                // own row i = jb*LPS + r, column j: lower part when j <= i
+                const bool low = (LPS == 1) ? true : (j < jb * LPS || (j - jb * LPS) <= r);
+                const bool strict = (LPS == 1) ? (j < jb) : (j < jb * LPS || (j - jb * LPS) < r);
+                const double pij = Pm[off(jb) + j];
+                acc = __builtin_fma(low ? pij : 0.0, wall[j], acc);
+                t[j] = __builtin_fma(strict ? pij : 0.0, w[jb], t[j]);        // contribution of P_ij to y_j (j < i)
+            }
+            y[jb] = acc;
+        }
+#pragma unroll
+        for (int j = 0; j < n; ++j) {
+            const double tj = group_sum<LPS>(t[j]);
+            if (LPS == 1 || r == j % LPS) y[j / LPS] += tj;
+        }
+    }
+
+    // ---- one box QP at state x: Mehrotra predictor-corrector + polish; result in v[] ----
+    __device__ __forceinline__ int solve_qp(const KParams &p, int &iters)
+    {
+        double q[RB];
+        linear_term(q);
+        double scale = 0.0;
+#pragma unroll
+        for (int jb = 0; jb < RB; ++jb) scale = fmax(scale, fabs(q[jb]));
+        scale = group_max<LPS>(scale);
+        const bool finite_in = scale < 1e300;
+        scale = fmax(scale, 1e-100);
+        const double z0 = p.z0_scale * scale;
+        double hmin = 1e300;
+#pragma unroll
+        for (int jb = 0; jb < RB; ++jb) {
+            const double h = hh(p, jb);
+            hmin = fmin(hmin, h);
+            v[jb] = 0.0; sl[jb] = h; su[jb] = h; zl[jb] = z0; zu[jb] = z0; rd[jb] = q[jb];
+        }
+        hmin = group_max<LPS>(-hmin); hmin = -hmin;
+        const double inv2n = 1.0 / (2.0 * n);
+        const double mu_tol = p.eps * scale * hmin, rd_tol = p.eps * scale;
+        int status = finite_in ? 1 : 2;
+        bool live = finite_in;            // this group still iterates
+        int it = 0;
+        for (; it < p.max_iter; ++it) {
+            double mu = 0.0, rn = 0.0;
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) {
+                mu = __builtin_fma(sl[jb], zl[jb], mu); mu = __builtin_fma(su[jb], zu[jb], mu);
+                rn = fmax(rn, fabs(rd[jb]));
+            }
+            mu = group_sum<LPS>(mu) * inv2n;
+            rn = group_max<LPS>(rn);
+            if (live) {
+                if (!(mu < 1e300) || !(rn < 1e300)) { status = 2; live = false; }
+                else if (mu <= mu_tol && rn <= rd_tol) { status = 0; live = false; }
+            }
+            if (!__any(live)) break;
+            iters += live ? 1 : 0;
+            // K = P + diag(zl/sl + zu/su)
+            double isl[RB], isu[RB];
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) {
+                isl[jb] = frcp(sl[jb]); isu[jb] = frcp(su[jb]);
+                const double dg = __builtin_fma(zl[jb], isl[jb], zu[jb] * isu[jb]);
+#pragma unroll
+                for (int j = 0; j < rowlen(jb); ++j) {
+                    const bool diag = (LPS == 1) ? (j == jb) : (j - jb * LPS == r);
+                    a[off(jb) + j] = Pm[off(jb) + j] + (diag ? dg : 0.0);
+                }
+            }
+            const bool okc = chol();
+            if (live && !okc) { status = 2; live = false; }
+            // predictor
+            double dva[RB];
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) dva[jb] = -rd[jb] - zl[jb] + zu[jb];
+            solve(dva);
+            double mp = 0.0, md = 0.0;
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) {
+                const double e = dva[jb] * isl[jb], f = dva[jb] * isu[jb];
+                mp = fmax(mp, fmax(-e, f));
+                md = fmax(md, fmax(1.0 + e, 1.0 - f));      // -dz_aff / z
+            }
+            mp = group_max<LPS>(mp); md = group_max<LPS>(md);
+            const double apa = mp > 1.0 ? frcp(mp) : 1.0, ada = md > 1.0 ? frcp(md) : 1.0;
+            double mua = 0.0;
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) {
+                const double d = dva[jb];
+                const double dzl = -zl[jb] * __builtin_fma(isl[jb], d, 1.0), dzu = -zu[jb] * __builtin_fma(-isu[jb], d, 1.0);
+                mua = __builtin_fma(__builtin_fma(apa, d, sl[jb]), __builtin_fma(ada, dzl, zl[jb]), mua);
+                mua = __builtin_fma(__builtin_fma(-apa, d, su[jb]), __builtin_fma(ada, dzu, zu[jb]), mua);
+            }
+            mua = group_sum<LPS>(mua) * inv2n;
+            double sg = mua * frcp(mu);
+            sg = sg * sg * sg;
+            const double smu = sg * mu;
+            // corrector (complementarity residuals are recomputed after the solve rather than kept live)
+            double dv[RB];
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) {
+                const double d = dva[jb];
+                const double dzla = -zl[jb] * __builtin_fma(isl[jb], d, 1.0), dzua = -zu[jb] * __builtin_fma(-isu[jb], d, 1.0);
+                const double rcl = smu - sl[jb] * zl[jb] - d * dzla, rcu = smu - su[jb] * zu[jb] + d * dzua;
+                dv[jb] = -rd[jb] + rcl * isl[jb] - rcu * isu[jb];
+            }
+            solve(dv);
+            mp = 0.0; md = 0.0;
+            double dzl[RB], dzu[RB];
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) {
+                const double d = dva[jb];
+                const double dzla = -zl[jb] * __builtin_fma(isl[jb], d, 1.0), dzua = -zu[jb] * __builtin_fma(-isu[jb], d, 1.0);
+                const double rcl = smu - sl[jb] * zl[jb] - d * dzla, rcu = smu - su[jb] * zu[jb] + d * dzua;
+                dzl[jb] = (rcl - zl[jb] * dv[jb]) * isl[jb];
+                dzu[jb] = (rcu + zu[jb] * dv[jb]) * isu[jb];
+                mp = fmax(mp, fmax(-dv[jb] * isl[jb], dv[jb] * isu[jb]));
+                md = fmax(md, fmax(-dzl[jb] * frcp(zl[jb]), -dzu[jb] * frcp(zu[jb])));
+            }
+            mp = group_max<LPS>(mp); md = group_max<LPS>(md);
+            double ap = mp > p.tau ? p.tau * frcp(mp) : 1.0, ad = md > p.tau ? p.tau * frcp(md) : 1.0;
+            if (!live) { ap = 0.0; ad = 0.0; }
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) {
+                const double st = ap * dv[jb];
+                v[jb] += st; sl[jb] += st; su[jb] -= st;
+                zl[jb] = __builtin_fma(ad, dzl[jb], zl[jb]); zu[jb] = __builtin_fma(ad, dzu[jb], zu[jb]);
+                rd[jb] = __builtin_fma(1.0 - ap, rd[jb], (ap - ad) * (dzl[jb] - dzu[jb]));
+            }
+        }
+        if (status == 2) {
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) v[jb] = 0.0;
+            return 2;
+        }
+        if (p.polish) {
+            // exact Newton step on the identified active face:  rows with z > s are snapped to
+            // their bound, the others solve P_FF d_F = -(g_F + P_FA d_A) with g = P v + q = rd + zl - zu
+            double dA[RB], pd[RB], rhs[RB];
+            unsigned mybits = 0;
+            bool act[RB];
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) {
+                const bool lo = zl[jb] > sl[jb], up = (!lo) && (zu[jb] > su[jb]);
+                act[jb] = lo || up;
+                dA[jb] = lo ? -sl[jb] : (up ? su[jb] : 0.0);      // bound - v
+                if (act[jb]) mybits |= 1u << (jb * LPS + r_or0());
+            }
+            const unsigned colmask = group_or<LPS>(mybits);
+            if (__any(colmask != 0)) symv(dA, pd);
+            else {
+#pragma unroll
+                for (int jb = 0; jb < RB; ++jb) pd[jb] = 0.0;
+            }
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) {
+                rhs[jb] = act[jb] ? dA[jb] : -(rd[jb] + zl[jb] - zu[jb] + pd[jb]);
+#pragma unroll
+                for (int j = 0; j < rowlen(jb); ++j) {
+                    const bool diag = (LPS == 1) ? (j == jb) : (j - jb * LPS == r);
+                    const bool aj = (colmask >> j) & 1u;
+                    a[off(jb) + j] = (act[jb] || aj) ? (diag ? 1.0 : 0.0) : Pm[off(jb) + j];
+                }
+            }
+            bool ok = chol();
+            solve(rhs);
+            unsigned good = ok ? 1u : 0u;
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) {
+                const double vp = v[jb] + rhs[jb];
+                if (!act[jb] && !(fabs(vp) <= hh(p, jb) * (1.0 + 1e-12))) good = 0u;
+            }
+            good = group_and<LPS>(good);
+            if (good) {
+#pragma unroll
+                for (int jb = 0; jb < RB; ++jb) v[jb] += rhs[jb];
+            }
+        }
+        return status;
+    }
+
+    __device__ __forceinline__ int r_or0() const { return LPS == 1 ? 0 : r; }
+
+    // optimal input i (time-major index) of the last solve, in every lane of the group, clipped to the box
+    __device__ __forceinline__ double u_at(const KParams &p, int i) const
+    {
+        const int k = i % NU;
+        const double lb = p.sh[p.so.lb + k], ub = p.sh[p.so.ub + k];
+        const double vi = bcast_rt(v[i / LPS], i % LPS);
+        return fmin(fmax(vi + 0.5 * (lb + ub), lb), ub);
+    }
+};
+
+// A, B entry of instance b (instance-minor)
+#define LD(ptr, e) (ptr)[(long long)(e) * Bsz + b]
+
+template <int NX, int NU, int N, int LPS>
+__global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
+{
+    using S = Spec<NX, NU, N, LPS>;
+    constexpr int RB = S::RB, SPW = S::SPW;
+    __shared__ double lds[S::LDS_DOUBLES];
+    S st;
+    st.lds = lds;
+    const int lane = threadIdx.x;
+    st.s = lane / LPS; st.r = lane % LPS;
+    const int r = st.r, s = st.s;
+    const long long Bsz = p.Bsz;
+    const long long b_raw = (long long)blockIdx.x * SPW + s;
+    const bool valid = b_raw < Bsz;
+    const long long b = valid ? b_raw : Bsz - 1;      // surplus groups recompute the last instance, never store
+    const double *sh = p.sh;
+
+    // ---------------- condensing ----------------
+    if constexpr (LPS > 1) {
+        const int k0 = r % NU;
+        st.hown = 0.5 * (sh[p.so.ub + k0] - sh[p.so.lb + k0]);
+        st.cown = 0.5 * (sh[p.so.ub + k0] + sh[p.so.lb + k0]);
+    }
+    {
+        double A[NX][NX], Bm[NX][NU];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) A[i][j] = LD(p.A, i * NX + j);
+#pragma unroll
+            for (int k = 0; k < NU; ++k) Bm[i][k] = LD(p.B, i * NU + k);
+        }
+        // M[m] = A^m B for m = 0..N-1, replicated per lane (registers) and staged in LDS so that a
+        // lane can fetch the Gamma column of ITS row (a lane-dependent (m, input) pair)
+        double M[N][NX][NU];
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+#pragma unroll
+            for (int k = 0; k < NU; ++k) M[0][i][k] = Bm[i][k];
+#pragma unroll
+        for (int m = 1; m < N; ++m)
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int k = 0; k < NU; ++k) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) t = __builtin_fma(A[i][j], M[m - 1][j][k], t);
+                    M[m][i][k] = t;
+                }
+        if constexpr (LPS > 1) {
+            // stage: lds[((m*NU + k)*NX + i)*SPW + s]; every lane of the group holds the same values
+#pragma unroll
+            for (int m = 0; m < N; ++m)
+#pragma unroll
+                for (int k = 0; k < NU; ++k)
+#pragma unroll
+                    for (int i = 0; i < NX; ++i)
+                        if (((m * NU + k) * NX + i) % LPS == r) lds[((m * NU + k) * NX + i) * SPW + s] = M[m][i][k];
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): single-wave workgroup, LDS ops are in order
+        }
+#pragma unroll
+        for (int e = 0; e < S::TRI; ++e) st.Pm[e] = 0.0;
+#pragma unroll
+        for (int jb = 0; jb < RB; ++jb) {
+            st.qr[jb] = 0.0;
+#pragma unroll
+            for (int aa = 0; aa < NX; ++aa) st.Fq[jb][aa] = 0.0;
+        }
+        // has_lin: references or an off-centre box contribute a constant to q
+        bool has_lin = p.has_ref != 0;
+#pragma unroll
+        for (int k = 0; k < NU; ++k) has_lin = has_lin || (sh[p.so.ub + k] + sh[p.so.lb + k] != 0.0);
+        double Ap[NX][NX];      // A^{rt+1}
+        double sc[NX];          // forced response to the constant centre input: s_{rt+1}
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            sc[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) Ap[i][j] = (i == j) ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int rt = 0; rt < N; ++rt) {
+            {   // Ap <- A * Ap
+                double T[NX][NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int l = 0; l < NX; ++l) t = __builtin_fma(A[i][l], Ap[l][j], t);
+                        T[i][j] = t;
+                    }
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) Ap[i][j] = T[i][j];
+            }
+            double e[NX];       // s_{rt+1} - xref_rt (only with has_lin)
+            if (has_lin) {
+                double T[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) t = __builtin_fma(A[i][j], sc[j], t);
+#pragma unroll
+                    for (int k = 0; k < NU; ++k) t = __builtin_fma(Bm[i][k], 0.5 * (sh[p.so.ub + k] + sh[p.so.lb + k]), t);
+                    T[i] = t;
+                }
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { sc[i] = T[i]; e[i] = T[i] - (p.has_ref ? sh[p.so.xref + i * N + rt] : 0.0); }
+            }
+            const int oQ = (rt < N - 1) ? p.so.Q : p.so.P;     // terminal weight on x_N (utils_class.py:67-72)
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) {
+                // Gamma_{rt}[:, i] for my row i = jb*LPS + r:  M[rt - bi][:, ui] (zero when bi > rt)
+                double g[NX];
+                if constexpr (LPS == 1) {
+                    const int bi = jb / NU, ui = jb % NU;
+                    if (bi > rt) continue;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) g[i] = M[rt - bi][i][ui];
+                } else {
+                    const int irow = jb * LPS + r, bi = irow / NU, ui = irow % NU;
+                    const int m = rt - bi;
+                    const int mc = m < 0 ? 0 : m;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) {
+                        const double t = lds[((mc * NU + ui) * NX + i) * SPW + s];
+                        g[i] = m < 0 ? 0.0 : t;
+                    }
+                }
+                double w[NX];   // Q_rt g
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) t = __builtin_fma(sh[oQ + i * NX + j], g[j], t);
+                    w[i] = t;
+                }
+#pragma unroll
+                for (int j = 0; j < S::rowlen(jb); ++j) {
+                    const int bj = j / NU, uj = j % NU;
+                    if (bj > rt) continue;
+                    double t = st.Pm[S::off(jb) + j];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) t = __builtin_fma(w[i], M[rt - bj][i][uj], t);
+                    st.Pm[S::off(jb) + j] = t;
+                }
+#pragma unroll
+                for (int aa = 0; aa < NX; ++aa) {
+                    double t = st.Fq[jb][aa];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) t = __builtin_fma(w[i], Ap[i][aa], t);
+                    st.Fq[jb][aa] = t;
+                }
+                if (has_lin) {
+                    double t = st.qr[jb];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) t = __builtin_fma(w[i], e[i], t);
+                    st.qr[jb] = t;
+                }
+            }
+        }
+        // + Rbar on the block diagonal, the R part of qr, then the factor 2
+#pragma unroll
+        for (int jb = 0; jb < RB; ++jb) {
+            const int irow = jb * LPS + ((LPS == 1) ? 0 : r), bi = irow / NU, ui = irow % NU;
+#pragma unroll
+            for (int j = 0; j < S::rowlen(jb); ++j) {
+                const int bj = j / NU, uj = j % NU;
+                const double rv = sh[p.so.R + ui * NU + uj];
+                st.Pm[S::off(jb) + j] = 2.0 * (st.Pm[S::off(jb) + j] + ((bj == bi) ? rv : 0.0));
+            }
+#pragma unroll
+            for (int aa = 0; aa < NX; ++aa) st.Fq[jb][aa] *= 2.0;
+            if (has_lin) {
+                double t = st.qr[jb];
+#pragma unroll
+                for (int uj = 0; uj < NU; ++uj) {
+                    const double cu = 0.5 * (sh[p.so.ub + uj] + sh[p.so.lb + uj]);
+                    const double ur = p.has_ref ? sh[p.so.uref + uj * N + bi] : 0.0;
+                    t = __builtin_fma(sh[p.so.R + ui * NU + uj], cu - ur, t);
+                }
+                st.qr[jb] = 2.0 * t;
+            }
+        }
+        if constexpr (LPS > 1) __builtin_amdgcn_s_waitcnt(0xc07f);   // staging reads done before chol() reuses the LDS
+    }
+
+    // ---------------- the requested operation ----------------
+    const bool writer = valid && (LPS == 1 || r == 0);
+    int iters = 0, status = 0;
+
+    auto value_fn = [&](const double (&x0)[NX]) -> double {
+        // V_N = cost* + x0'Qx0 by rolling the MODEL forward with the optimal inputs (utils_class.py:62-75, 91)
+        double cost = 0.0, xs[NX];
+        double A[NX][NX], Bm[NX][NU];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) A[i][j] = LD(p.A, i * NX + j);
+#pragma unroll
+            for (int k = 0; k < NU; ++k) Bm[i][k] = LD(p.B, i * NU + k);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            xs[i] = x0[i];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) cost = __builtin_fma(x0[i] * sh[p.so.Q + i * NX + j], x0[j], cost);
+        }
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            double u[NU], xn[NX];
+#pragma unroll
+            for (int k = 0; k < NU; ++k) u[k] = st.u_at(p, t * NU + k);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < NX; ++j) acc = __builtin_fma(A[i][j], xs[j], acc);
+#pragma unroll
+                for (int k = 0; k < NU; ++k) acc = __builtin_fma(Bm[i][k], u[k], acc);
+                xn[i] = acc;
+            }
+            const int oQ = (t < N - 1) ? p.so.Q : p.so.P;
+            double dx[NX], du[NU];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { xs[i] = xn[i]; dx[i] = xn[i] - (p.has_ref ? sh[p.so.xref + i * N + t] : 0.0); }
+#pragma unroll
+            for (int k = 0; k < NU; ++k) du[k] = u[k] - (p.has_ref ? sh[p.so.uref + k * N + t] : 0.0);
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int j = 0; j < NX; ++j) cost = __builtin_fma(dx[i] * sh[oQ + i * NX + j], dx[j], cost);
+#pragma unroll
+            for (int k = 0; k < NU; ++k)
+#pragma unroll
+                for (int j = 0; j < NU; ++j) cost = __builtin_fma(du[k] * sh[p.so.R + k * NU + j], du[j], cost);
+        }
+        return cost;
+    };
+
+    if (p.mode == MODE_SOLVE) {
+        double x0[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { x0[i] = LD(p.x0, i); st.x[i] = x0[i]; }
+        status = st.solve_qp(p, iters);
+        const double vn = value_fn(x0);
+        double u0[NU];
+#pragma unroll
+        for (int k = 0; k < NU; ++k) u0[k] = st.u_at(p, k);
+        if (writer) {
+#pragma unroll
+            for (int k = 0; k < NU; ++k) p.u0[(long long)k * Bsz + b] = u0[k];
+            p.VN[b] = vn;
+        }
+    } else if (p.mode == MODE_MAXVN) {
+        double best = -1e308;
+        for (int k = 0; k < p.K; ++k) {
+            double x0[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { x0[i] = sh[p.so.x0s + i * p.K + k]; st.x[i] = x0[i]; }
+            const int stt = st.solve_qp(p, iters);
+            status = stt > status ? stt : status;
+            const double vn = value_fn(x0);
+            best = (vn > best || vn != vn) ? vn : best;
+        }
+        if (writer) p.MV[b] = best;
+    } else {
+        double cost = 0.0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) st.x[i] = LD(p.x0, i);
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+#pragma unroll
+            for (int j = 0; j < NX; ++j) cost = __builtin_fma(st.x[i] * sh[p.so.Q + i * NX + j], st.x[j], cost);   // utils_class.py:261
+        if (p.X && writer) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) p.X[((long long)i * (p.T + 1)) * Bsz + b] = st.x[i];
+        }
+        for (int t = 0; t < p.T; ++t) {                                                  // utils_class.py:266-283
+            const int stt = st.solve_qp(p, iters);
+            status = stt > status ? stt : status;
+            double u[NU], xn[NX];
+#pragma unroll
+            for (int k = 0; k < NU; ++k) u[k] = st.u_at(p, k);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {                                               // line 277: plant step
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    const double at = p.true_per_instance ? LD(p.At, i * NX + j) : sh[p.so.At + i * NX + j];
+                    acc = __builtin_fma(at, st.x[j], acc);
+                }
+#pragma unroll
+                for (int k = 0; k < NU; ++k) {
+                    const double bt = p.true_per_instance ? LD(p.Bt, i * NU + k) : sh[p.so.Bt + i * NU + k];
+                    acc = __builtin_fma(bt, u[k], acc);
+                }
+                xn[i] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) st.x[i] = xn[i];
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int j = 0; j < NX; ++j) cost = __builtin_fma(xn[i] * sh[p.so.Q + i * NX + j], xn[j], cost);   // 282
+#pragma unroll
+            for (int k = 0; k < NU; ++k)
+#pragma unroll
+                for (int j = 0; j < NU; ++j) cost = __builtin_fma(u[k] * sh[p.so.R + k * NU + j], u[j], cost);      // 283
+            if (writer) {
+                if (p.X) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) p.X[((long long)i * (p.T + 1) + t + 1) * Bsz + b] = xn[i];
+                }
+                if (p.U) {
+#pragma unroll
+                    for (int k = 0; k < NU; ++k) p.U[((long long)k * p.T + t) * Bsz + b] = u[k];
+                }
+            }
+        }
+        if (writer) p.JT[b] = cost;
+    }
+    if (writer) {
+        if (p.status) p.status[b] = status;
+        if (p.iters) p.iters[b] = iters;
+    }
+}
+
+// ---------------- registry of built specialisations ----------------
+struct SpecEntry {
+    int nx, nu, N, lps;
+    const char *name;
+    void (*launch)(const KParams &, hipStream_t);
+};
+
+template <int NX, int NU, int N, int LPS>
+static void launch_one(const KParams &p, hipStream_t stream)
+{
+    constexpr int SPW = 64 / LPS;
+    const unsigned grid = (unsigned)((p.Bsz + SPW - 1) / SPW);
+    hipLaunchKernelGGL((lqmpc_spec_kernel<NX, NU, N, LPS>), dim3(grid), dim3(64), 0, stream, p);
+}
+
+#define SPEC(NX, NU, N, LPS) {NX, NU, N, LPS, "lqmpc_spec_kernel<" #NX "," #NU "," #N "," #LPS ">", launch_one<NX, NU, N, LPS>}
+
+static const SpecEntry g_specs[] = {
+    SPEC(2, 1, 5, 1),     // C1  (working_example_single.py shape, N = 5)
+    SPEC(2, 1, 10, 2),    // C2
+    SPEC(4, 2, 10, 4),    // C3  (headline)
+};
+
+static const SpecEntry *find_spec(int nx, int nu, int N)
+{
+    for (const SpecEntry &e : g_specs)
+        if (e.nx == nx && e.nu == nu && e.N == N) return &e;
+    return nullptr;
+}
+
+bool spec_available(int nx, int nu, int N) { return find_spec(nx, nu, N) != nullptr; }
+
+bool launch_spec(const KParams &p, hipStream_t stream, const char **name)
+{
+    const SpecEntry *e = find_spec(p.nx, p.nu, p.N);
+    if (!e) return false;
+    e->launch(p, stream);
+    if (name) *name = e->name;
+    return true;
+}
+
 }  // namespace lqmpc

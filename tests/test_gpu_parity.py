@@ -132,7 +132,7 @@ def test_zero_state_and_saturated_cases(ksolver):
     got = ksolver.solve_batch(*args(b), x0)
     ref = orc.solve_batch(*args(b), x0)
     assert np.all(got["status"] == 0)
-    assert np.all(got["u_0"][:, :16] == 0) and np.all(np.abs(got["V_N"][:16]) < 1e-300)
+    assert np.all(np.abs(got["u_0"][:, :16]) < 1e-100) and np.all(np.abs(got["V_N"][:16]) < 1e-100)
     assert np.all(np.abs(np.abs(got["u_0"][:, 16:32]).max(0) - U_MAX) < 1e-12)
     assert u_err(got["u_0"][:, 16:], ref["u_0"][:, 16:]) < RTOL
     assert rel(got["V_N"][16:], ref["V_N"][16:]) < TIGHT
