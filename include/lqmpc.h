@@ -78,7 +78,10 @@ typedef struct lqmpc_options {
     int32_t max_iter;  /* interior-point iteration cap per QP (default 50) */
     int32_t polish;    /* 1: finish with an exact solve on the identified active set (default 1) */
     int32_t kernel;    /* enum lqmpc_kernel (default AUTO) */
-    int32_t reserved;
+    int32_t presolve;  /* unconstrained-minimiser shortcut: the minimiser v = G x + v_r (G = -P^-1 Fq, built once
+                          per instance) is tested against the box before any iteration; a QP whose minimiser is
+                          interior is finished there, exactly.  -1 auto (on for rollouts, off for one-shot calls),
+                          0 off, 1 on.  Specialised kernels only; the generic kernel ignores it.  (default -1) */
 } lqmpc_options;
 
 /* Limits of this build. */

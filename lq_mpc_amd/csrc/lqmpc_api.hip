@@ -87,7 +87,7 @@ void lqmpc_default_options(lqmpc_options *opt)
     opt->max_iter = 50;
     opt->polish = 1;
     opt->kernel = LQMPC_KERNEL_AUTO;
-    opt->reserved = 0;
+    opt->presolve = -1;
 }
 
 int lqmpc_create_on_stream(int device, void *hip_stream, lqmpc_handle **out)
@@ -152,6 +152,7 @@ int lqmpc_set_options(lqmpc_handle *h, const lqmpc_options *opt)
     if (!(opt->z0_scale > 0.0)) return fail(LQMPC_ERR_BAD_ARG, "z0_scale must be positive");
     if (opt->max_iter < 1 || opt->max_iter > 1000) return fail(LQMPC_ERR_BAD_ARG, "max_iter must be in [1,1000]");
     if (opt->kernel < LQMPC_KERNEL_AUTO || opt->kernel > LQMPC_KERNEL_SPECIALIZED) return fail(LQMPC_ERR_BAD_ARG, "unknown kernel selector");
+    if (opt->presolve < -1 || opt->presolve > 1) return fail(LQMPC_ERR_BAD_ARG, "presolve must be -1, 0 or 1");
     h->opt = *opt;
     return 0;
 }
@@ -236,6 +237,7 @@ static int prepare(lqmpc_handle *h, const Call &c, KParams &p)
     p.true_per_instance = c.true_per_instance;
     p.has_ref = (c.x_ref || c.u_ref) ? 1 : 0;
     p.max_iter = h->opt.max_iter; p.polish = h->opt.polish;
+    p.presolve = h->opt.presolve < 0 ? (c.mode == lqmpc::MODE_ROLLOUT ? 1 : 0) : h->opt.presolve;
     p.eps = h->opt.eps; p.tau = h->opt.tau; p.z0_scale = h->opt.z0_scale;
     p.Bsz = c.Bsz;
     p.sh = (const double *)h->shared.p;

@@ -75,6 +75,28 @@ __device__ __forceinline__ unsigned group_and(unsigned x)
     return x;
 }
 
+// ---------------- read-mostly per-lane data parked in the accumulator register file ----------------
+// gfx950 has one 512-entry register file per lane, but VALU instructions address only the first
+// 256 (VGPRs); the upper half (AGPRs) is reachable with v_accvgpr_read/write.  The constant rows
+// of P and Fq are read once per interior-point iteration / once per QP, so they are pinned there
+// explicitly ("a" constraint) and the allocator keeps the VGPR half for the Cholesky working set.
+template <int CNT>
+struct AccArr {
+    int lo[CNT], hi[CNT];
+    __device__ __forceinline__ void set(int i, double x)
+    {
+        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(lo[i]) : "v"(__double2loint(x)));
+        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(hi[i]) : "v"(__double2hiint(x)));
+    }
+    __device__ __forceinline__ double get(int i) const
+    {
+        int l, h;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(l) : "a"(lo[i]));
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(h) : "a"(hi[i]));
+        return __hiloint2double(h, l);
+    }
+};
+
 // ---------------- the kernel, specialised on the problem shape ----------------
 template <int NX, int NU, int N, int LPS>
 struct Spec {
@@ -87,41 +109,46 @@ struct Spec {
     static constexpr int TRI = LPS * RB * (RB + 1) / 2;
     __host__ __device__ static constexpr int off(int jb) { return LPS * jb * (jb + 1) / 2; }
     __host__ __device__ static constexpr int rowlen(int jb) { return (jb + 1) * LPS; }
-    // LDS mirror of L, column-major: column c holds row-blocks jb >= c/LPS, each 64 doubles
-    // ([instance][sub-lane]); column starts are skewed by c doubles so that the backward
-    // substitution's reads (4 lanes of a group in 4 different columns) hit distinct banks.
+    // LDS mirror of L, column-major: column c holds row-blocks jb >= c/LPS, 64 doubles each.
+    // Inside a 64-double block the element of instance s, row-sub-lane rr sits at
+    // s*LPS + (rr ^ (c % LPS)): the Cholesky's column writes (all lanes in one column) and the
+    // backward substitution's reads (the LPS lanes of a group in LPS different columns, same row)
+    // both touch 64 distinct slots -- bank-conflict-free without padding, so that mirror + Fq fill
+    // the wave's 40 KiB share of LDS exactly (4 waves per CU = 160 KiB).
     __host__ __device__ static constexpr int colstart(int c)
     {
         int s = 0;
         for (int cc = 0; cc < c; ++cc) s += (RB - cc / LPS) * 64;
-        return s + c;
+        return s;
     }
     static constexpr int MIRROR = (LPS == 1) ? 0 : colstart(n);
-    static constexpr int STAGE = (LPS == 1) ? 0 : N * NX * NU * SPW;
-    static constexpr int LDS_DOUBLES = MIRROR > STAGE ? MIRROR : (STAGE > 0 ? STAGE : 1);
+    static constexpr int STAGE = N * NX * NU * SPW;            // A^m B staging during condensing (aliases the mirror)
+    static constexpr int FQ0 = MIRROR > STAGE ? MIRROR : STAGE; // Fq rows: [(jb*NX + a)*64 + lane]
+    static constexpr int LDS_DOUBLES = FQ0 + RB * NX * 64;
 
     // ---- per-lane state (all in VGPRs) ----
-    double Pm[TRI];        // own rows of P, row-block jb padded to rowlen(jb) columns
+    AccArr<TRI> Pm;        // own rows of P, row-block jb padded to rowlen(jb) columns (AGPRs)
     double a[TRI];         // K, then L; diagonal blocks are zero on and above the diagonal after chol()
     double invd[RB];       // 1 / l_ii of own rows
-    double Fq[RB][NX];     // own rows of 2 Gamma' Qbar Phi
-    double qr[RB];         // own rows of the constant part of q (references, box centre)
-    double v[RB], sl[RB], su[RB], zl[RB], zu[RB], rd[RB];
+    AccArr<RB> qr;         // own rows of the constant part of q (references, box centre); with presolve: of v_r = -P^-1 qr
+    AccArr<RB> qs;         // q of the QP being solved (kept for the polish)
+    double sl[RB], su[RB], zl[RB], zu[RB], rd[RB];   // interior-point state; v = sl - h is implied
+    double v[RB];          // result of the last QP (shifted inputs), set at the end of solve_qp
     double x[NX];          // current state (replicated in the group)
-    double hown, cown;     // half-width / centre of own rows' input (LPS > 1: same input for all own rows)
-    int r, s;              // sub-lane in group, group in wave
+    AccArr<2> hc;          // half-width / centre of own rows' input (LPS > 1: same input for all own rows)
+    int r, s, lane;        // sub-lane in group, group in wave, lane in wave
     double *lds;
 
     // half-width and centre of own row jb
     __device__ __forceinline__ double hh(const KParams &p, int jb) const
     {
         if constexpr (LPS == 1) { const int k = jb % NU; return 0.5 * (p.sh[p.so.ub + k] - p.sh[p.so.lb + k]); }
-        else return hown;
+        else return hc.get(0);
     }
     __device__ __forceinline__ double cc(const KParams &p, int jb) const
     {
         if constexpr (LPS == 1) { const int k = jb % NU; return 0.5 * (p.sh[p.so.ub + k] + p.sh[p.so.lb + k]); }
-        else return cown;
+        else return hc.get(1);
     }
 
     // ---- in-place Cholesky of the row-distributed matrix in a[] (right-looking, column k) ----
@@ -145,7 +172,7 @@ struct Spec {
             for (int jb = kb + 1; jb < RB; ++jb) a[off(jb) + k] *= inv;
             if constexpr (LPS > 1) {
 #pragma unroll
-                for (int jb = kb; jb < RB; ++jb) lds[colstart(k) + ((jb - kb) * SPW + s) * LPS + r] = a[off(jb) + k];
+                for (int jb = kb; jb < RB; ++jb) lds[colstart(k) + (jb - kb) * 64 + s * LPS + (r ^ kr)] = a[off(jb) + k];
             }
             // trailing update: a[i][c] -= l_ik * l_ck for c > k, rows i >= c
 #pragma unroll
@@ -155,6 +182,7 @@ struct Spec {
 #pragma unroll
                 for (int jb = cb; jb < RB; ++jb) a[off(jb) + c] = __builtin_fma(-a[off(jb) + k], lck, a[off(jb) + c]);
             }
+            if constexpr (LPS > 1) { if (k % LPS == LPS - 1) __builtin_amdgcn_sched_barrier(0); }
         }
         return ok;
     }
@@ -188,6 +216,7 @@ struct Spec {
                 if (LPS == 1 && jb == kb) continue;   // its own row
                 b[jb] = __builtin_fma(-a[off(jb) + k], yk, b[jb]);   // diagonal block: zeros for rows <= k
             }
+            if constexpr (LPS > 1) { if (k % LPS == LPS - 1) __builtin_amdgcn_sched_barrier(0); }
         }
 #pragma unroll
         for (int jb = 0; jb < RB; ++jb) b[jb] *= invd[jb];
@@ -202,29 +231,28 @@ struct Spec {
                     if (jb == kb) continue;
                     b[jb] = __builtin_fma(-a[off(kb) + jb], xk, b[jb]);       // l_{k,jb} from my own row k
                 } else {
-                    // l_{k,i} for my column i = jb*LPS + r: mirror column i, row k
-                    // = colstart(jb*LPS + r) + ((kb - jb)*SPW + s)*LPS + kr   (zero when i >= k)
-                    const double lki = lds[colstart_r(jb) + ((kb - jb) * SPW + s) * LPS + kr];
+                    // l_{k,i} for my column i = jb*LPS + r: mirror column i, row k (zero when i >= k)
+                    const double lki = lds[colstart_r(jb) + (kb - jb) * 64 + s * LPS + (kr ^ r)];
                     b[jb] = __builtin_fma(-lki, xk, b[jb]);
                 }
             }
+            if constexpr (LPS > 1) { if (k % LPS == 0) __builtin_amdgcn_sched_barrier(0); }
         }
 #pragma unroll
         for (int jb = 0; jb < RB; ++jb) b[jb] *= invd[jb];
     }
 
-    // colstart(jb*LPS + r) for the run-time sub-lane r: the per-column sizes are equal inside a
-    // row-block, so it is colstart(jb*LPS) + r * ((RB - jb)*64 + 1)
-    __device__ __forceinline__ int colstart_r(int jb) const { return colstart(jb * LPS) + r * ((RB - jb) * 64 + 1); }
+    // colstart(jb*LPS + r) for the run-time sub-lane r: the columns of one row-block have equal sizes
+    __device__ __forceinline__ int colstart_r(int jb) const { return colstart(jb * LPS) + r * ((RB - jb) * 64); }
 
     // ---- q = Fq x + qr for own rows ----
     __device__ __forceinline__ void linear_term(double (&q)[RB]) const
     {
 #pragma unroll
         for (int jb = 0; jb < RB; ++jb) {
-            double t = qr[jb];
+            double t = qr.get(jb);
 #pragma unroll
-            for (int aa = 0; aa < NX; ++aa) t = __builtin_fma(Fq[jb][aa], x[aa], t);
+            for (int aa = 0; aa < NX; ++aa) t = __builtin_fma(lds[FQ0 + (jb * NX + aa) * 64 + lane], x[aa], t);
             q[jb] = t;
         }
     }
@@ -232,27 +260,24 @@ struct Spec {
     // ---- y = P w for a row-distributed w (symmetric product from the stored lower part) ----
     __device__ __forceinline__ void symv(const double (&w)[RB], double (&y)[RB]) const
     {
-        double wall[n], t[n];
 #pragma unroll
-        for (int j = 0; j < n; ++j) { wall[j] = bcast_rt(w[j / LPS], j % LPS); t[j] = 0.0; }
-#pragma unroll
-        for (int jb = 0; jb < RB; ++jb) {
-            double acc = 0.0;
-#pragma unroll
-            for (int j = 0; j < rowlen(jb); ++j) {
-                // own row i = jb*LPS + r, column j: lower part when j <= i
-                const bool low = (LPS == 1) ? true : (j < jb * LPS || (j - jb * LPS) <= r);
-                const bool strict = (LPS == 1) ? (j < jb) : (j < jb * LPS || (j - jb * LPS) < r);
-                const double pij = Pm[off(jb) + j];
-                acc = __builtin_fma(low ? pij : 0.0, wall[j], acc);
-                t[j] = __builtin_fma(strict ? pij : 0.0, w[jb], t[j]);        // contribution of P_ij to y_j (j < i)
-            }
-            y[jb] = acc;
-        }
+        for (int jb = 0; jb < RB; ++jb) y[jb] = 0.0;
 #pragma unroll
         for (int j = 0; j < n; ++j) {
-            const double tj = group_sum<LPS>(t[j]);
+            // column j: lower part adds P_ij w_j to my rows i >= j; upper part adds P_ij w_i (i > j) to y_j
+            const double wj = bcast_rt(w[j / LPS], j % LPS);
+            double tj = 0.0;
+#pragma unroll
+            for (int jb = j / LPS; jb < RB; ++jb) {
+                const bool low = (LPS == 1) ? true : (jb * LPS > j || r >= j - jb * LPS);        // i >= j
+                const bool strict = (LPS == 1) ? (jb > j) : (jb * LPS > j || r > j - jb * LPS);  // i >  j
+                const double pij = Pm.get(off(jb) + j);
+                y[jb] = __builtin_fma(low ? pij : 0.0, wj, y[jb]);
+                tj = __builtin_fma(strict ? pij : 0.0, w[jb], tj);
+            }
+            tj = group_sum<LPS>(tj);
             if (LPS == 1 || r == j % LPS) y[j / LPS] += tj;
+            if constexpr (LPS > 1) { if (j % LPS == LPS - 1) __builtin_amdgcn_sched_barrier(0); }
         }
     }
 
@@ -261,6 +286,26 @@ struct Spec {
     {
         double q[RB];
         linear_term(q);
+        bool inside = false;
+        if (p.presolve) {
+            // LDS holds G = -P^-1 Fq and qr holds v_r: q is the unconstrained minimiser v_unc = G x + v_r.
+            unsigned in = 1u;
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) {
+                v[jb] = q[jb];
+                if (!(fabs(q[jb]) <= hh(p, jb))) in = 0u;
+            }
+            in = group_and<LPS>(in);
+            inside = in != 0u;
+            if (!__any(!inside)) return 0;           // every instance of the wave is done, exactly
+            double y[RB];
+            symv(q, y);                              // q = -P v_unc for the instances that must iterate
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) q[jb] = -y[jb];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int jb = 0; jb < RB; ++jb) qs.set(jb, q[jb]);
         double scale = 0.0;
 #pragma unroll
         for (int jb = 0; jb < RB; ++jb) scale = fmax(scale, fabs(q[jb]));
@@ -273,13 +318,13 @@ struct Spec {
         for (int jb = 0; jb < RB; ++jb) {
             const double h = hh(p, jb);
             hmin = fmin(hmin, h);
-            v[jb] = 0.0; sl[jb] = h; su[jb] = h; zl[jb] = z0; zu[jb] = z0; rd[jb] = q[jb];
+            sl[jb] = h; su[jb] = h; zl[jb] = z0; zu[jb] = z0; rd[jb] = q[jb];
         }
         hmin = group_max<LPS>(-hmin); hmin = -hmin;
         const double inv2n = 1.0 / (2.0 * n);
         const double mu_tol = p.eps * scale * hmin, rd_tol = p.eps * scale;
-        int status = finite_in ? 1 : 2;
-        bool live = finite_in;            // this group still iterates
+        int status = inside ? 0 : (finite_in ? 1 : 2);
+        bool live = finite_in && !inside; // this group still iterates
         int it = 0;
         for (; it < p.max_iter; ++it) {
             double mu = 0.0, rn = 0.0;
@@ -305,10 +350,12 @@ struct Spec {
 #pragma unroll
                 for (int j = 0; j < rowlen(jb); ++j) {
                     const bool diag = (LPS == 1) ? (j == jb) : (j - jb * LPS == r);
-                    a[off(jb) + j] = Pm[off(jb) + j] + (diag ? dg : 0.0);
+                    a[off(jb) + j] = Pm.get(off(jb) + j) + (diag ? dg : 0.0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             const bool okc = chol();
+            __builtin_amdgcn_sched_barrier(0);
             if (live && !okc) { status = 2; live = false; }
             // predictor
             double dva[RB];
@@ -364,59 +411,79 @@ struct Spec {
 #pragma unroll
             for (int jb = 0; jb < RB; ++jb) {
                 const double st = ap * dv[jb];
-                v[jb] += st; sl[jb] += st; su[jb] -= st;
+                sl[jb] += st; su[jb] -= st;
                 zl[jb] = __builtin_fma(ad, dzl[jb], zl[jb]); zu[jb] = __builtin_fma(ad, dzu[jb], zu[jb]);
                 rd[jb] = __builtin_fma(1.0 - ap, rd[jb], (ap - ad) * (dzl[jb] - dzu[jb]));
             }
         }
         if (status == 2) {
 #pragma unroll
-            for (int jb = 0; jb < RB; ++jb) v[jb] = 0.0;
-            return 2;
+            for (int jb = 0; jb < RB; ++jb) sl[jb] = hh(p, jb);      // v = 0 below
         }
+        bool polished = false;
         if (p.polish) {
-            // exact Newton step on the identified active face:  rows with z > s are snapped to
-            // their bound, the others solve P_FF d_F = -(g_F + P_FA d_A) with g = P v + q = rd + zl - zu
-            double dA[RB], pd[RB], rhs[RB];
+            // exact solve on the identified active face: rows with z > s sit on their bound (v = -h or +h),
+            // the others solve P_FF v_F = -(q_F + P_FA v_A).  Solving for v itself (not for a correction)
+            // keeps full relative precision when the optimum is tiny compared with the box.
+            double rhs[RB];
             unsigned mybits = 0;
-            bool act[RB];
 #pragma unroll
             for (int jb = 0; jb < RB; ++jb) {
                 const bool lo = zl[jb] > sl[jb], up = (!lo) && (zu[jb] > su[jb]);
-                act[jb] = lo || up;
-                dA[jb] = lo ? -sl[jb] : (up ? su[jb] : 0.0);      // bound - v
-                if (act[jb]) mybits |= 1u << (jb * LPS + r_or0());
+                const double h = hh(p, jb);
+                rhs[jb] = lo ? -h : (up ? h : 0.0);
+                if (lo || up) mybits |= 1u << (jb * LPS + r_or0());
             }
             const unsigned colmask = group_or<LPS>(mybits);
-            if (__any(colmask != 0)) symv(dA, pd);
-            else {
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                double q[RB];
 #pragma unroll
-                for (int jb = 0; jb < RB; ++jb) pd[jb] = 0.0;
+                for (int jb = 0; jb < RB; ++jb) q[jb] = qs.get(jb);
+                if (__any(colmask != 0)) {
+                    double pd[RB];
+                    symv(rhs, pd);
+#pragma unroll
+                    for (int jb = 0; jb < RB; ++jb)
+                        if (!((mybits >> (jb * LPS + r_or0())) & 1u)) rhs[jb] = -(q[jb] + pd[jb]);
+                } else {
+#pragma unroll
+                    for (int jb = 0; jb < RB; ++jb) rhs[jb] = -q[jb];
+                }
             }
 #pragma unroll
             for (int jb = 0; jb < RB; ++jb) {
-                rhs[jb] = act[jb] ? dA[jb] : -(rd[jb] + zl[jb] - zu[jb] + pd[jb]);
+                const bool ai = (mybits >> (jb * LPS + r_or0())) & 1u;
 #pragma unroll
                 for (int j = 0; j < rowlen(jb); ++j) {
                     const bool diag = (LPS == 1) ? (j == jb) : (j - jb * LPS == r);
                     const bool aj = (colmask >> j) & 1u;
-                    a[off(jb) + j] = (act[jb] || aj) ? (diag ? 1.0 : 0.0) : Pm[off(jb) + j];
+                    const double pv = Pm.get(off(jb) + j);     // read unconditionally: no branch per element
+                    a[off(jb) + j] = (ai || aj) ? (diag ? 1.0 : 0.0) : pv;
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            bool ok = chol();
+            const bool ok = chol();
+            __builtin_amdgcn_sched_barrier(0);
             solve(rhs);
             unsigned good = ok ? 1u : 0u;
 #pragma unroll
             for (int jb = 0; jb < RB; ++jb) {
-                const double vp = v[jb] + rhs[jb];
-                if (!act[jb] && !(fabs(vp) <= hh(p, jb) * (1.0 + 1e-12))) good = 0u;
+                const bool ai = (mybits >> (jb * LPS + r_or0())) & 1u;
+                if (!ai && !(fabs(rhs[jb]) <= hh(p, jb) * (1.0 + 1e-12))) good = 0u;
             }
             good = group_and<LPS>(good);
-            if (good) {
+            polished = good != 0u && status != 2;
+            if (polished) {
 #pragma unroll
-                for (int jb = 0; jb < RB; ++jb) v[jb] += rhs[jb];
+                for (int jb = 0; jb < RB; ++jb) v[jb] = rhs[jb];
             }
         }
+        if (!polished) {
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) v[jb] = sl[jb] - hh(p, jb);
+        }
+        if (inside) linear_term(v);                  // presolve: this instance's answer is its v_unc
         return status;
     }
 
@@ -435,16 +502,16 @@ struct Spec {
 // A, B entry of instance b (instance-minor)
 #define LD(ptr, e) (ptr)[(long long)(e) * Bsz + b]
 
-template <int NX, int NU, int N, int LPS>
+template <int NX, int NU, int N, int LPS, int MODE>
 __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
 {
     using S = Spec<NX, NU, N, LPS>;
-    constexpr int RB = S::RB, SPW = S::SPW;
+    constexpr int n = S::n, RB = S::RB, SPW = S::SPW;
     __shared__ double lds[S::LDS_DOUBLES];
     S st;
     st.lds = lds;
     const int lane = threadIdx.x;
-    st.s = lane / LPS; st.r = lane % LPS;
+    st.s = lane / LPS; st.r = lane % LPS; st.lane = lane;
     const int r = st.r, s = st.s;
     const long long Bsz = p.Bsz;
     const long long b_raw = (long long)blockIdx.x * SPW + s;
@@ -453,10 +520,14 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
     const double *sh = p.sh;
 
     // ---------------- condensing ----------------
+    // H = sum_rt Gamma_rt' Q_rt Gamma_rt + Rbar with Gamma_rt[:, j] = M[rt - bj][:, uj], M[m] = A^m B.
+    // M lives in LDS ([m][input][state][instance]); a lane fetches the Gamma column of ITS row with a
+    // lane-dependent address and the columns of the other side with group-uniform addresses, so
+    // no A^m B table is held in registers.
     if constexpr (LPS > 1) {
         const int k0 = r % NU;
-        st.hown = 0.5 * (sh[p.so.ub + k0] - sh[p.so.lb + k0]);
-        st.cown = 0.5 * (sh[p.so.ub + k0] + sh[p.so.lb + k0]);
+        st.hc.set(0, 0.5 * (sh[p.so.ub + k0] - sh[p.so.lb + k0]));
+        st.hc.set(1, 0.5 * (sh[p.so.ub + k0] + sh[p.so.lb + k0]));
     }
     {
         double A[NX][NX], Bm[NX][NU];
@@ -467,42 +538,50 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
 #pragma unroll
             for (int k = 0; k < NU; ++k) Bm[i][k] = LD(p.B, i * NU + k);
         }
-        // M[m] = A^m B for m = 0..N-1, replicated per lane (registers) and staged in LDS so that a
-        // lane can fetch the Gamma column of ITS row (a lane-dependent (m, input) pair)
-        double M[N][NX][NU];
-#pragma unroll
-        for (int i = 0; i < NX; ++i)
-#pragma unroll
-            for (int k = 0; k < NU; ++k) M[0][i][k] = Bm[i][k];
-#pragma unroll
-        for (int m = 1; m < N; ++m)
+        // stage M[m][k][i] at lds[((m*NU + k)*NX + i)*SPW + s]; every lane of a group computes the same
+        // chain, sub-lane (e % LPS) stores element e
+        {
+            double Mc[NX][NU];
 #pragma unroll
             for (int i = 0; i < NX; ++i)
 #pragma unroll
-                for (int k = 0; k < NU; ++k) {
-                    double t = 0.0;
+                for (int k = 0; k < NU; ++k) Mc[i][k] = Bm[i][k];
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) t = __builtin_fma(A[i][j], M[m - 1][j][k], t);
-                    M[m][i][k] = t;
+            for (int m = 0; m < N; ++m) {
+                if (m > 0) {
+                    double T[NX][NU];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i)
+#pragma unroll
+                        for (int k = 0; k < NU; ++k) {
+                            double t = 0.0;
+#pragma unroll
+                            for (int j = 0; j < NX; ++j) t = __builtin_fma(A[i][j], Mc[j][k], t);
+                            T[i][k] = t;
+                        }
+#pragma unroll
+                    for (int i = 0; i < NX; ++i)
+#pragma unroll
+                        for (int k = 0; k < NU; ++k) Mc[i][k] = T[i][k];
                 }
-        if constexpr (LPS > 1) {
-            // stage: lds[((m*NU + k)*NX + i)*SPW + s]; every lane of the group holds the same values
-#pragma unroll
-            for (int m = 0; m < N; ++m)
 #pragma unroll
                 for (int k = 0; k < NU; ++k)
 #pragma unroll
-                    for (int i = 0; i < NX; ++i)
-                        if (((m * NU + k) * NX + i) % LPS == r) lds[((m * NU + k) * NX + i) * SPW + s] = M[m][i][k];
-            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): single-wave workgroup, LDS ops are in order
+                    for (int i = 0; i < NX; ++i) {
+                        const int e = (m * NU + k) * NX + i;
+                        if (LPS == 1 || e % LPS == r) lds[e * SPW + s] = Mc[i][k];
+                    }
+            }
         }
+        double Pacc[S::TRI], Facc[RB][NX];
 #pragma unroll
-        for (int e = 0; e < S::TRI; ++e) st.Pm[e] = 0.0;
+        for (int e = 0; e < S::TRI; ++e) Pacc[e] = 0.0;
+        double qacc[RB];
 #pragma unroll
         for (int jb = 0; jb < RB; ++jb) {
-            st.qr[jb] = 0.0;
+            qacc[jb] = 0.0;
 #pragma unroll
-            for (int aa = 0; aa < NX; ++aa) st.Fq[jb][aa] = 0.0;
+            for (int aa = 0; aa < NX; ++aa) Facc[jb][aa] = 0.0;
         }
         // has_lin: references or an off-centre box contribute a constant to q
         bool has_lin = p.has_ref != 0;
@@ -516,7 +595,7 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
 #pragma unroll
             for (int j = 0; j < NX; ++j) Ap[i][j] = (i == j) ? 1.0 : 0.0;
         }
-#pragma unroll
+#pragma unroll 1
         for (int rt = 0; rt < N; ++rt) {
             {   // Ap <- A * Ap
                 double T[NX][NX];
@@ -550,54 +629,54 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
                 for (int i = 0; i < NX; ++i) { sc[i] = T[i]; e[i] = T[i] - (p.has_ref ? sh[p.so.xref + i * N + rt] : 0.0); }
             }
             const int oQ = (rt < N - 1) ? p.so.Q : p.so.P;     // terminal weight on x_N (utils_class.py:67-72)
+            // w[jb] = Q_rt * Gamma_rt[:, my row of block jb]
+            double w[RB][NX];
 #pragma unroll
             for (int jb = 0; jb < RB; ++jb) {
-                // Gamma_{rt}[:, i] for my row i = jb*LPS + r:  M[rt - bi][:, ui] (zero when bi > rt)
+                const int irow = jb * LPS + ((LPS == 1) ? 0 : r), bi = irow / NU, ui = irow % NU;
+                const int m = rt - bi;
+                const int mc = m < 0 ? 0 : m;
                 double g[NX];
-                if constexpr (LPS == 1) {
-                    const int bi = jb / NU, ui = jb % NU;
-                    if (bi > rt) continue;
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) g[i] = M[rt - bi][i][ui];
-                } else {
-                    const int irow = jb * LPS + r, bi = irow / NU, ui = irow % NU;
-                    const int m = rt - bi;
-                    const int mc = m < 0 ? 0 : m;
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) {
-                        const double t = lds[((mc * NU + ui) * NX + i) * SPW + s];
-                        g[i] = m < 0 ? 0.0 : t;
-                    }
+                for (int i = 0; i < NX; ++i) {
+                    const double t = lds[((mc * NU + ui) * NX + i) * SPW + s];
+                    g[i] = m < 0 ? 0.0 : t;
                 }
-                double w[NX];   // Q_rt g
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
                     double t = 0.0;
 #pragma unroll
                     for (int j = 0; j < NX; ++j) t = __builtin_fma(sh[oQ + i * NX + j], g[j], t);
-                    w[i] = t;
-                }
-#pragma unroll
-                for (int j = 0; j < S::rowlen(jb); ++j) {
-                    const int bj = j / NU, uj = j % NU;
-                    if (bj > rt) continue;
-                    double t = st.Pm[S::off(jb) + j];
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) t = __builtin_fma(w[i], M[rt - bj][i][uj], t);
-                    st.Pm[S::off(jb) + j] = t;
+                    w[jb][i] = t;
                 }
 #pragma unroll
                 for (int aa = 0; aa < NX; ++aa) {
-                    double t = st.Fq[jb][aa];
+                    double t = Facc[jb][aa];
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) t = __builtin_fma(w[i], Ap[i][aa], t);
-                    st.Fq[jb][aa] = t;
+                    for (int i = 0; i < NX; ++i) t = __builtin_fma(w[jb][i], Ap[i][aa], t);
+                    Facc[jb][aa] = t;
                 }
                 if (has_lin) {
-                    double t = st.qr[jb];
+                    double t = qacc[jb];
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) t = __builtin_fma(w[i], e[i], t);
-                    st.qr[jb] = t;
+                    for (int i = 0; i < NX; ++i) t = __builtin_fma(w[jb][i], e[i], t);
+                    qacc[jb] = t;
+                }
+            }
+            // P[my rows][j] += w . Gamma_rt[:, j] for every column j with bj <= rt
+#pragma unroll
+            for (int j = 0; j < n; ++j) {
+                const int bj = j / NU, uj = j % NU;
+                if (bj > rt) continue;       // wave-uniform
+                double mcol[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) mcol[i] = lds[(((rt - bj) * NU + uj) * NX + i) * SPW + s];
+#pragma unroll
+                for (int jb = j / LPS; jb < RB; ++jb) {
+                    double t = Pacc[S::off(jb) + j];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) t = __builtin_fma(w[jb][i], mcol[i], t);
+                    Pacc[S::off(jb) + j] = t;
                 }
             }
         }
@@ -609,22 +688,40 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
             for (int j = 0; j < S::rowlen(jb); ++j) {
                 const int bj = j / NU, uj = j % NU;
                 const double rv = sh[p.so.R + ui * NU + uj];
-                st.Pm[S::off(jb) + j] = 2.0 * (st.Pm[S::off(jb) + j] + ((bj == bi) ? rv : 0.0));
+                st.Pm.set(S::off(jb) + j, 2.0 * (Pacc[S::off(jb) + j] + ((bj == bi) ? rv : 0.0)));
             }
 #pragma unroll
-            for (int aa = 0; aa < NX; ++aa) st.Fq[jb][aa] *= 2.0;
+            for (int aa = 0; aa < NX; ++aa) lds[S::FQ0 + (jb * NX + aa) * 64 + lane] = 2.0 * Facc[jb][aa];
+            double tq = qacc[jb];
             if (has_lin) {
-                double t = st.qr[jb];
 #pragma unroll
                 for (int uj = 0; uj < NU; ++uj) {
                     const double cu = 0.5 * (sh[p.so.ub + uj] + sh[p.so.lb + uj]);
                     const double ur = p.has_ref ? sh[p.so.uref + uj * N + bi] : 0.0;
-                    t = __builtin_fma(sh[p.so.R + ui * NU + uj], cu - ur, t);
+                    tq = __builtin_fma(sh[p.so.R + ui * NU + uj], cu - ur, tq);
                 }
-                st.qr[jb] = 2.0 * t;
+            }
+            st.qr.set(jb, 2.0 * tq);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (p.presolve) {
+        // G = -P^-1 Fq (one column per state) and v_r = -P^-1 qr overwrite Fq and qr
+#pragma unroll
+        for (int e = 0; e < S::TRI; ++e) st.a[e] = st.Pm.get(e);
+        st.chol();
+        __builtin_amdgcn_sched_barrier(0);
+        for (int aa = 0; aa <= NX; ++aa) {
+            double col[RB];
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) col[jb] = (aa < NX) ? lds[S::FQ0 + (jb * NX + aa) * 64 + lane] : st.qr.get(jb);
+            st.solve(col);
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) {
+                if (aa < NX) lds[S::FQ0 + (jb * NX + aa) * 64 + lane] = -col[jb];
+                else st.qr.set(jb, -col[jb]);
             }
         }
-        if constexpr (LPS > 1) __builtin_amdgcn_s_waitcnt(0xc07f);   // staging reads done before chol() reuses the LDS
     }
 
     // ---------------- the requested operation ----------------
@@ -680,7 +777,7 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
         return cost;
     };
 
-    if (p.mode == MODE_SOLVE) {
+    if constexpr (MODE == MODE_SOLVE) {
         double x0[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) { x0[i] = LD(p.x0, i); st.x[i] = x0[i]; }
@@ -694,7 +791,7 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
             for (int k = 0; k < NU; ++k) p.u0[(long long)k * Bsz + b] = u0[k];
             p.VN[b] = vn;
         }
-    } else if (p.mode == MODE_MAXVN) {
+    } else if constexpr (MODE == MODE_MAXVN) {
         double best = -1e308;
         for (int k = 0; k < p.K; ++k) {
             double x0[NX];
@@ -724,20 +821,32 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
             double u[NU], xn[NX];
 #pragma unroll
             for (int k = 0; k < NU; ++k) u[k] = st.u_at(p, k);
+            // line 277: plant step.  The plant is re-read every step (scalar loads when shared, L2-resident
+            // vector loads when per-instance) instead of being held in registers across the QP; the opaque
+            // copies of the loop counter / base pointers keep the compiler from hoisting 24 addresses out
+            // of the step loop.
+            long long tb = b;
+            asm volatile("" : "+v"(tb));
+            if (p.true_per_instance) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) {                                               // line 277: plant step
-                double acc = 0.0;
+                for (int i = 0; i < NX; ++i) {
+                    double acc = 0.0;
 #pragma unroll
-                for (int j = 0; j < NX; ++j) {
-                    const double at = p.true_per_instance ? LD(p.At, i * NX + j) : sh[p.so.At + i * NX + j];
-                    acc = __builtin_fma(at, st.x[j], acc);
+                    for (int j = 0; j < NX; ++j) acc = __builtin_fma(p.At[(long long)(i * NX + j) * Bsz + tb], st.x[j], acc);
+#pragma unroll
+                    for (int k = 0; k < NU; ++k) acc = __builtin_fma(p.Bt[(long long)(i * NU + k) * Bsz + tb], u[k], acc);
+                    xn[i] = acc;
                 }
+            } else {
 #pragma unroll
-                for (int k = 0; k < NU; ++k) {
-                    const double bt = p.true_per_instance ? LD(p.Bt, i * NU + k) : sh[p.so.Bt + i * NU + k];
-                    acc = __builtin_fma(bt, u[k], acc);
+                for (int i = 0; i < NX; ++i) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) acc = __builtin_fma(sh[p.so.At + i * NX + j], st.x[j], acc);
+#pragma unroll
+                    for (int k = 0; k < NU; ++k) acc = __builtin_fma(sh[p.so.Bt + i * NU + k], u[k], acc);
+                    xn[i] = acc;
                 }
-                xn[i] = acc;
             }
 #pragma unroll
             for (int i = 0; i < NX; ++i) st.x[i] = xn[i];
@@ -752,11 +861,11 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
             if (writer) {
                 if (p.X) {
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) p.X[((long long)i * (p.T + 1) + t + 1) * Bsz + b] = xn[i];
+                    for (int i = 0; i < NX; ++i) p.X[((long long)i * (p.T + 1) + t + 1) * Bsz + tb] = xn[i];
                 }
                 if (p.U) {
 #pragma unroll
-                    for (int k = 0; k < NU; ++k) p.U[((long long)k * p.T + t) * Bsz + b] = u[k];
+                    for (int k = 0; k < NU; ++k) p.U[((long long)k * p.T + t) * Bsz + tb] = u[k];
                 }
             }
         }
@@ -780,7 +889,12 @@ static void launch_one(const KParams &p, hipStream_t stream)
 {
     constexpr int SPW = 64 / LPS;
     const unsigned grid = (unsigned)((p.Bsz + SPW - 1) / SPW);
-    hipLaunchKernelGGL((lqmpc_spec_kernel<NX, NU, N, LPS>), dim3(grid), dim3(64), 0, stream, p);
+    if (p.mode == MODE_SOLVE)
+        hipLaunchKernelGGL((lqmpc_spec_kernel<NX, NU, N, LPS, MODE_SOLVE>), dim3(grid), dim3(64), 0, stream, p);
+    else if (p.mode == MODE_MAXVN)
+        hipLaunchKernelGGL((lqmpc_spec_kernel<NX, NU, N, LPS, MODE_MAXVN>), dim3(grid), dim3(64), 0, stream, p);
+    else
+        hipLaunchKernelGGL((lqmpc_spec_kernel<NX, NU, N, LPS, MODE_ROLLOUT>), dim3(grid), dim3(64), 0, stream, p);
 }
 
 #define SPEC(NX, NU, N, LPS) {NX, NU, N, LPS, "lqmpc_spec_kernel<" #NX "," #NU "," #N "," #LPS ">", launch_one<NX, NU, N, LPS>}
