@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--mode", choices=["rollout", "oneshot"], default="rollout")
     ap.add_argument("--kernel", choices=["auto", "generic", "specialized"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (box share: 16 per GPU)")
     ap.add_argument("--no-oneshot", action="store_true", help="skip the extra one-shot measurement")
     args = ap.parse_args()
 
@@ -87,7 +88,7 @@ def main():
     dVN = torch.empty(Bsz, dtype=torch.float64, device=dev)
     dst = torch.empty(Bsz, dtype=torch.int32, device=dev)
     dit = torch.empty(Bsz, dtype=torch.int32, device=dev)
-    gathered = torch.empty(world * Bsz, dtype=torch.float64, device=dev) if world > 1 else None
+    from lq_mpc_amd import dist as ld
 
     stream = torch.cuda.current_stream(dev).cuda_stream
     kern = {"auto": 0, "generic": 1, "specialized": 2}[args.kernel]
@@ -110,7 +111,7 @@ def main():
             if ev is not None:
                 ev[1].record()
             if world > 1:
-                dist.all_gather_into_tensor(gathered, dJT)
+                ld.all_gather_costs(dJT, world * Bsz)       # RCCL all-gather of the cost curve
         for _ in range(warmup):
             one_step()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -181,7 +182,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
-        cores = len(os.sched_getaffinity(0))
+        cores = max(1, min(len(os.sched_getaffinity(0)), args.cpu_threads))
         def cpu_run(m):
             A = np.ascontiguousarray(b["A"][:, :, :m]); Bm = np.ascontiguousarray(b["B"][:, :, :m])
             x0 = np.ascontiguousarray(b["x0"][:, :m])

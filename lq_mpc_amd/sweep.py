@@ -1,0 +1,110 @@
+"""Batched counterpart of the reference's multi-system sweep (the batch axis of the hot path).
+
+Mirrors LQ_RDP_Behavior_Multiple (/root/reference/utils_class.py:685-959) for the part of
+data_generation that is the MPC hot path:
+    V_expert            utils_class.py:786
+    M_V (max of 8 V_N)  utils_class.py:813-824, 896-907
+    true_cost_error     utils_class.py:828-833
+    true_cost_horizon   utils_class.py:911-916
+The reference issues 57 001 sequential cvxpy solves for this; here every (error level, system) pair
+is one instance of ONE batched launch per horizon, read straight from the reference's .npy files
+(their memory layout already is the library's instance-minor layout, utils_class.py:749-750).
+The scalar bound coefficients alpha/beta/xi (utils_class.py:837-859) are outside the hot path
+(SURVEY.md 8(f) "next") and are not produced here.
+"""
+import math
+import os
+
+import numpy as np
+
+from .mpc import box_from_Fu, default_solver
+
+
+def dlqr_gain(A, B, Q, R):
+    """K of control.dlqr (u = -K x), via scipy's DARE (utils_class.py:761)."""
+    from scipy.linalg import solve_discrete_are
+    Pinf = solve_discrete_are(A, B, Q, R)
+    return np.linalg.solve(R + B.T @ Pinf @ B, B.T @ Pinf @ A)
+
+
+def local_radius(F_u, K, Q):
+    """epsilon_K = 1 / max_i |(F_u K)_i|^2_{Q^-1}   (utils.py:548-564)."""
+    M = np.asarray(F_u) @ np.asarray(K)
+    invQ = np.linalg.inv(Q)
+    return 1.0 / max(float(M[i] @ invQ @ M[i]) for i in range(M.shape[0]))
+
+
+def circle_generator(N_points, ratio_ext_radius, my_base, Q):
+    """Points on x'Qx = (ratio*sqrt(base))^2; 2-state systems only, as utils.py:683-704."""
+    Q = np.asarray(Q, dtype=np.float64)
+    if Q.shape != (2, 2):
+        raise ValueError("circle_generator is defined for n_x = 2 (utils.py:683-704)")
+    root_Q = np.linalg.cholesky(Q).T            # scipy cho_factor's default (upper) factor
+    base = np.array([ratio_ext_radius * math.sqrt(my_base), 0.0])
+    theta = np.linspace(0, 2 * (1 - 1 / N_points) * math.pi, N_points)
+    pts = np.stack([np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]]) @ base for t in theta], axis=1)
+    return np.linalg.inv(root_Q) @ pts
+
+
+class LQ_RDP_Behavior_Multiple:
+    """Same constructor arguments as utils_class.py:691-692 (plus data_dir / solver)."""
+
+    def __init__(self, info_opc, info_N, info_e_pow, N_sys, norm_type, errM_import=True, data_dir=".", solver=None):
+        self.A_true = np.asarray(info_opc["A"], dtype=np.float64)
+        self.B_true = np.asarray(info_opc["B"], dtype=np.float64)
+        self.Q = np.asarray(info_opc["Q"], dtype=np.float64)
+        self.R = np.asarray(info_opc["R"], dtype=np.float64)
+        self.F_u = np.asarray(info_opc["F_u"], dtype=np.float64)
+        self.lb, self.ub = box_from_Fu(self.F_u)
+        self.N_sys = 5 * N_sys                                   # utils_class.py:726
+        self.N_min, self.N_max = info_N["N_min"], info_N["N_max"]
+        self.N_nominal, self.N_opc, self.N_mpc = info_N["N_nominal"], info_N["N_opc"], info_N["N_mpc"]
+        self.e_min, self.e_max, self.e_nominal = info_e_pow["e_min"], info_e_pow["e_max"], info_e_pow["e_nominal"]
+        self.horizon = np.arange(self.N_min, self.N_max + 1)
+        self.error_vec = np.linspace(self.e_min, self.e_max, 10)
+        if not errM_import:
+            raise NotImplementedError("the reference's unseeded perturbation generator (utils.py:760-847) is out of scope; "
+                                      "pass the shipped error_{A,B}_<norm>.npy files")
+        self.error_A = np.load(os.path.join(data_dir, f"error_A_{norm_type}.npy"))      # (nx, nx, N_sys, 10)
+        self.error_B = np.load(os.path.join(data_dir, f"error_B_{norm_type}.npy"))      # (nx, nu, N_sys, 10)
+        self._solver = solver
+        K_lqr = dlqr_gain(self.A_true, self.B_true, self.Q, self.R)
+        self.epsilon_lqr = local_radius(self.F_u, -K_lqr, self.Q)                        # utils_class.py:764
+
+    def _s(self):
+        return self._solver if self._solver is not None else default_solver()
+
+    def data_generation(self, N_points, ext_radius_max, info_ref, p=None):
+        s = self._s()
+        nx, nu = self.B_true.shape
+        Q, R, lb, ub = self.Q, self.R, self.lb, self.ub
+        x0_vec = circle_generator(N_points, ext_radius_max, self.epsilon_lqr, Q)         # utils_class.py:782
+        x_start = x0_vec[:, 1]                                                            # utils_class.py:783
+        V_expert = float(s.solve_batch(self.N_opc, self.A_true[:, :, None], self.B_true[:, :, None], Q, R, Q, lb, ub,
+                                       x_start[:, None], info_ref.get("x_ref_long"), info_ref.get("u_ref_long"))["V_N"][0])
+        n_err = len(self.error_vec)
+        # error sweep: every (system j, level i) pair is one instance; the file layout is (.., j, i)
+        A = np.ascontiguousarray((self.A_true[:, :, None, None] + self.error_A).reshape(nx, nx, -1))
+        B = np.ascontiguousarray((self.B_true[:, :, None, None] + self.error_B).reshape(nx, nu, -1))
+        Bsz = A.shape[2]
+        x0 = np.repeat(x_start[:, None], Bsz, axis=1)
+        N = self.N_nominal
+        M_V_error = s.max_vn_batch(N, A, B, Q, R, Q, lb, ub, x0_vec, info_ref.get("x_ref"), info_ref.get("u_ref"))["M_V"]
+        J = s.rollout_batch(self.N_mpc, N, A, B, Q, R, Q, lb, ub, x0, self.A_true, self.B_true,
+                            info_ref.get("x_ref"), info_ref.get("u_ref"))["J_T"]
+        true_cost_error = J.reshape(self.N_sys, n_err)
+        M_V_error = M_V_error.reshape(self.N_sys, n_err)
+        # horizon sweep on error column index_sys = 4 (utils_class.py:880-883), zero references (887-888)
+        A4 = np.ascontiguousarray(self.A_true[:, :, None] + self.error_A[:, :, :, 4])
+        B4 = np.ascontiguousarray(self.B_true[:, :, None] + self.error_B[:, :, :, 4])
+        x04 = np.repeat(x_start[:, None], self.N_sys, axis=1)
+        true_cost_horizon = np.zeros((self.N_sys, len(self.horizon)))
+        M_V_horizon = np.zeros((self.N_sys, len(self.horizon)))
+        for i, Nh in enumerate(self.horizon):
+            Nh = int(Nh)
+            M_V_horizon[:, i] = s.max_vn_batch(Nh, A4, B4, Q, R, Q, lb, ub, x0_vec)["M_V"]
+            true_cost_horizon[:, i] = s.rollout_batch(self.N_mpc, Nh, A4, B4, Q, R, Q, lb, ub, x04,
+                                                      self.A_true, self.B_true)["J_T"]
+        return {"error": self.error_vec, "horizon": self.horizon, "V_expert": V_expert,
+                "true_cost_error": true_cost_error, "true_cost_horizon": true_cost_horizon,
+                "M_V_error": M_V_error, "M_V_horizon": M_V_horizon, "x0_vec": x0_vec}

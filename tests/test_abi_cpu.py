@@ -68,3 +68,19 @@ def test_product_path_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+def test_sweep_host_helpers_match_reference_constants():
+    """circle_generator / local_radius / dlqr restated for the product's sweep driver (SURVEY 8(c) constants)."""
+    from lq_mpc_amd import sweep
+    A0 = np.array([[1.0, 0.7], [0.12, 0.4]]); B0 = np.array([[1.0], [1.2]])
+    Q, R = 2.0 * np.eye(2), np.eye(1)
+    F_u = np.vstack((10 * np.eye(1), -10 * np.eye(1)))
+    K = sweep.dlqr_gain(A0, B0, Q, R)
+    np.testing.assert_allclose(K, [[0.48363093, 0.45846723]], rtol=1e-7)
+    eps = sweep.local_radius(F_u, -K, Q)
+    assert abs(eps - 0.04503580745099056) < 1e-15
+    x0 = sweep.circle_generator(8, 1.5, eps, Q)
+    np.testing.assert_allclose(x0[:, 1], [0.15916231240837822, 0.15916231240837819], rtol=1e-14)
+    with pytest.raises(ValueError):
+        sweep.circle_generator(8, 1.5, eps, np.eye(3))

@@ -226,3 +226,26 @@ def test_presolve_and_polish_options_agree(solver, cfg, golden_dir):
         assert rel(got["J_T"], ref["J_T"]) < RTOL and u_err(got["U"], ref["U"]) < RTOL
     finally:
         solver.set_options(presolve=-1, polish=1, eps=1e-12)
+
+
+# ---------------- the batch caller: data_generation's hot half ----------------
+def test_data_generation_reproduces_reference_npz(solver, golden_dir):
+    """working_example_multiple.py:13-58, 70-76 constants -> utils_class.py:766-833, 861-916."""
+    from lq_mpc_amd.sweep import LQ_RDP_Behavior_Multiple
+    info_opc = {"A": A0, "B": B0, "Q": Q2, "R": R1, "F_u": F_U}
+    info_N = {"N_min": 6, "N_max": 10, "N_nominal": 7, "N_opc": 30, "N_mpc": 30}
+    info_e = {"e_min": 1e-3, "e_max": 1e-2, "e_nominal": 5e-3}
+    info_ref = {"x_ref": np.zeros((2, 7)), "u_ref": np.zeros((1, 7)), "x_ref_long": np.zeros((2, 30)), "u_ref_long": np.zeros((1, 30))}
+    beh = LQ_RDP_Behavior_Multiple(info_opc, info_N, info_e, 20, "f", data_dir=golden_dir, solver=solver)
+    out = beh.data_generation(8, 1.5, info_ref, np.array([0.1, 1, 0.6]))
+    d = np.load(os.path.join(golden_dir, "data_lq_mpc_multipleSys.npz"))
+    np.testing.assert_allclose(out["error"], d["error"]); np.testing.assert_array_equal(out["horizon"], d["horizon"])
+    assert abs(out["V_expert"] - float(d["V_expert"])) / float(d["V_expert"]) < 1e-10
+    assert rel(out["true_cost_error"], d["true_cost_error"]) < 1e-10
+    assert rel(out["true_cost_horizon"], d["true_cost_horizon"]) < 1e-10
+    # M_V is not in the npz (only through xi); pin it against the oracle
+    eA = np.load(os.path.join(golden_dir, "error_A_f.npy")); eB = np.load(os.path.join(golden_dir, "error_B_f.npy"))
+    A = (A0[:, :, None, None] + eA).reshape(2, 2, 1000); B = (B0[:, :, None, None] + eB).reshape(2, 1, 1000)
+    mv = orc.max_vn_batch(7, A, B, Q2, R1, Q2, [-0.1], [0.1], out["x0_vec"]).reshape(100, 10)
+    assert rel(out["M_V_error"], mv) < TIGHT
+    assert np.all(out["M_V_error"] / beh.epsilon_lqr > 4.0) and np.all(out["M_V_error"] / beh.epsilon_lqr < 5.0)   # SURVEY 8(c)
