@@ -82,6 +82,12 @@ typedef struct lqmpc_options {
                           per instance) is tested against the box before any iteration; a QP whose minimiser is
                           interior is finished there, exactly.  -1 auto (on for rollouts, off for one-shot calls),
                           0 off, 1 on.  Specialised kernels only; the generic kernel ignores it.  (default -1) */
+    int32_t order;     /* processing order of a rollout batch.  1: a probe launch computes per instance how far the
+                          unconstrained minimiser at x0 leaves the box, the batch is radix-sorted by that key and the
+                          rollout walks it hardest-first, so the instances that share a wavefront leave the constrained
+                          regime together (results are written back to their original positions).  0: natural order.
+                          -1 auto (1 for specialised rollouts with presolve, T >= 4 and Bsz >= 1024).  (default -1) */
+    int32_t reserved;
 } lqmpc_options;
 
 /* Limits of this build. */

@@ -3,6 +3,8 @@
 #include "lqmpc_common.h"
 #include "../../include/lqmpc.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -45,6 +47,7 @@ struct lqmpc_handle {
     bool own_stream = false;
     lqmpc_options opt;
     DevBuf shared, ws;
+    DevBuf key, key_sorted, idx, perm, cub_tmp;   // difficulty ordering of rollout batches
     DevBuf stage[12];                // host-flavour staging (inputs and outputs)
     std::vector<double> shared_host; // last uploaded shared block
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -88,6 +91,8 @@ void lqmpc_default_options(lqmpc_options *opt)
     opt->polish = 1;
     opt->kernel = LQMPC_KERNEL_AUTO;
     opt->presolve = -1;
+    opt->order = -1;
+    opt->reserved = 0;
 }
 
 int lqmpc_create_on_stream(int device, void *hip_stream, lqmpc_handle **out)
@@ -129,6 +134,7 @@ int lqmpc_destroy(lqmpc_handle *h)
     (void)hipStreamSynchronize(h->stream);
     if (h->shared.p) (void)hipFree(h->shared.p);
     if (h->ws.p) (void)hipFree(h->ws.p);
+    for (DevBuf *b : {&h->key, &h->key_sorted, &h->idx, &h->perm, &h->cub_tmp}) if (b->p) (void)hipFree(b->p);
     for (auto &b : h->stage) if (b.p) (void)hipFree(b.p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -153,6 +159,7 @@ int lqmpc_set_options(lqmpc_handle *h, const lqmpc_options *opt)
     if (opt->max_iter < 1 || opt->max_iter > 1000) return fail(LQMPC_ERR_BAD_ARG, "max_iter must be in [1,1000]");
     if (opt->kernel < LQMPC_KERNEL_AUTO || opt->kernel > LQMPC_KERNEL_SPECIALIZED) return fail(LQMPC_ERR_BAD_ARG, "unknown kernel selector");
     if (opt->presolve < -1 || opt->presolve > 1) return fail(LQMPC_ERR_BAD_ARG, "presolve must be -1, 0 or 1");
+    if (opt->order < -1 || opt->order > 1) return fail(LQMPC_ERR_BAD_ARG, "order must be -1, 0 or 1");
     h->opt = *opt;
     return 0;
 }
@@ -253,6 +260,41 @@ static int prepare(lqmpc_handle *h, const Call &c, KParams &p)
     return 0;
 }
 
+__global__ void lqmpc_iota_kernel(int *idx, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx[i] = i;
+}
+
+// Difficulty ordering (options.order): probe launch -> key per instance -> radix sort, hardest first.
+// On success p.perm points at the permutation (slot -> instance).
+static int build_order(lqmpc_handle *h, KParams &p)
+{
+    const size_t B = (size_t)p.Bsz;
+    if (B > (size_t)INT32_MAX) return fail(LQMPC_ERR_BAD_ARG, "ordering supports up to 2^31-1 instances");
+    int rc = ensure(h, h->key, B * sizeof(double));
+    if (!rc) rc = ensure(h, h->key_sorted, B * sizeof(double));
+    if (!rc) rc = ensure(h, h->idx, B * sizeof(int));
+    if (!rc) rc = ensure(h, h->perm, B * sizeof(int));
+    if (rc) return rc;
+    size_t tmp_bytes = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, (const double *)h->key.p, (double *)h->key_sorted.p,
+                                                         (const int *)h->idx.p, (int *)h->perm.p, (int)B, 0, 64, h->stream));
+    rc = ensure(h, h->cub_tmp, tmp_bytes);
+    if (rc) return rc;
+    KParams q = p;
+    q.mode = lqmpc::MODE_PROBE;
+    q.perm = nullptr;
+    q.key = (double *)h->key.p;
+    const char *name = nullptr;
+    if (!lqmpc::launch_spec(q, h->stream, &name)) return fail(LQMPC_ERR_UNSUPPORTED, "probe launch failed");
+    hipLaunchKernelGGL(lqmpc_iota_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, (int *)h->idx.p, (int)B);
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(h->cub_tmp.p, tmp_bytes, (const double *)h->key.p, (double *)h->key_sorted.p,
+                                                         (const int *)h->idx.p, (int *)h->perm.p, (int)B, 0, 64, h->stream));
+    p.perm = (const int *)h->perm.p;
+    return 0;
+}
+
 static int launch(lqmpc_handle *h, const KParams &p)
 {
     const char *name = "lqmpc_generic_kernel";
@@ -313,6 +355,12 @@ int lqmpc_rollout_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
     if (rc) return rc;
     p.A = dA; p.B = dB; p.x0 = dx0; p.JT = dJT; p.X = dX; p.U = dU; p.status = dstatus; p.iters = diters;
     if (true_per_instance) { p.At = A_true; p.Bt = B_true; }
+    const bool spec = use_spec(h, nx, nu, N);
+    const int order = h->opt.order < 0 ? ((spec && p.presolve && T >= 4 && Bsz >= 1024) ? 1 : 0) : (spec ? h->opt.order : 0);
+    if (order) {
+        rc = build_order(h, p);
+        if (rc) return rc;
+    }
     return launch(h, p);
 }
 

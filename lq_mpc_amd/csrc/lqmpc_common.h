@@ -6,7 +6,7 @@
 
 namespace lqmpc {
 
-enum Mode : int { MODE_SOLVE = 0, MODE_ROLLOUT = 1, MODE_MAXVN = 2 };
+enum Mode : int { MODE_SOLVE = 0, MODE_ROLLOUT = 1, MODE_MAXVN = 2, MODE_PROBE = 3 };
 
 // Offsets (in doubles) into the small "shared" device block that holds the data common to the
 // whole batch: Q, R, P, lb, ub, x_ref (nx,N), u_ref (nu,N), A_true, B_true, x0s (nx,K).
@@ -29,6 +29,8 @@ struct KParams {
     double *ws;                           // generic kernel workspace (device)
     double *u0, *VN, *JT, *X, *U, *MV;    // outputs (device; X, U may be null)
     int *status, *iters;                  // may be null
+    const int *perm;                      // processing order (slot -> instance), null = natural order
+    double *key;                          // MODE_PROBE output: difficulty key per instance
 };
 
 // ---- fp64 reciprocal / reciprocal square root: hardware seed + Newton steps ----

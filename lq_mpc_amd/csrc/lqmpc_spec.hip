@@ -154,16 +154,22 @@ struct Spec {
     // ---- in-place Cholesky of the row-distributed matrix in a[] (right-looking, column k) ----
     // On exit: strict lower part = L, invd = 1/diag(L), diagonal blocks zero on/above the
     // diagonal, and (LPS > 1) L mirrored into LDS column-major.  Returns false on a bad pivot.
+    //
+    // Cross-lane traffic of step k (LPS > 1): every lane needs l_ck for all c > k.  Only l_{k+1,k}
+    // travels by DPP -- it feeds the look-ahead update of column k+1 and so the next pivot, whose
+    // rsqrt chain then overlaps the rest of the step; all other l_ck are read back from the column
+    // just written to the LDS mirror (group-uniform addresses, two values per ds_read_b128), which
+    // costs a quarter of the VALU slots of a DPP broadcast and whose latency the look-ahead hides.
     __device__ __forceinline__ bool chol()
     {
+        typedef double d2_t __attribute__((ext_vector_type(2)));
         bool ok = true;
+        double d = bcast_rt(a[off(0)], 0);
+        double inv = frsqrt(d);
+        ok = ok && (d > 0.0);
 #pragma unroll
         for (int k = 0; k < n; ++k) {
             const int kb = k / LPS, kr = k % LPS;
-            double d = a[off(kb) + k];
-            d = bcast_rt(d, kr);
-            ok = ok && (d > 0.0);
-            const double inv = frsqrt(d);
             if (LPS == 1 || r == kr) invd[kb] = inv;
             // scale column k: rows below the diagonal; zero the diagonal block on/above it
             if constexpr (LPS == 1) a[off(kb) + k] = 0.0;
@@ -174,14 +180,43 @@ struct Spec {
 #pragma unroll
                 for (int jb = kb; jb < RB; ++jb) lds[colstart(k) + (jb - kb) * 64 + s * LPS + (r ^ kr)] = a[off(jb) + k];
             }
-            // trailing update: a[i][c] -= l_ik * l_ck for c > k, rows i >= c
-#pragma unroll
-            for (int c = k + 1; c < n; ++c) {
-                const int cb = c / LPS, cr = c % LPS;
+            double inv_next = 0.0;
+            if (k + 1 < n) {
+                // look-ahead: finish column k+1, then start the next pivot's reciprocal square root
+                const int c = k + 1, cb = c / LPS, cr = c % LPS;
                 const double lck = bcast_rt(a[off(cb) + k], cr);
 #pragma unroll
                 for (int jb = cb; jb < RB; ++jb) a[off(jb) + c] = __builtin_fma(-a[off(jb) + k], lck, a[off(jb) + c]);
+                d = bcast_rt(a[off(cb) + c], cr);
+                ok = ok && (d > 0.0);
+                inv_next = frsqrt(d);
             }
+            // trailing update of the columns c >= k+2: a[i][c] -= l_ik * l_ck, rows i >= c
+            if constexpr (LPS == 1) {
+#pragma unroll
+                for (int c = k + 2; c < n; ++c) {
+                    const double lck = a[off(c) + k];
+#pragma unroll
+                    for (int jb = c; jb < RB; ++jb) a[off(jb) + c] = __builtin_fma(-a[off(jb) + k], lck, a[off(jb) + c]);
+                }
+            } else {
+#pragma unroll
+                for (int c0 = (k + 2) & ~1; c0 < n; c0 += 2) {
+                    // columns c0, c0+1 sit in one aligned pair of the mirror block (positions cr ^ kr)
+                    const int cb = c0 / LPS, pr = c0 % LPS;
+                    const d2_t pair = *reinterpret_cast<const d2_t *>(&lds[colstart(k) + (cb - kb) * 64 + s * LPS + (pr ^ (kr & ~1))]);
+                    const double l0 = (kr & 1) ? pair.y : pair.x, l1 = (kr & 1) ? pair.x : pair.y;
+                    if (c0 >= k + 2) {
+#pragma unroll
+                        for (int jb = cb; jb < RB; ++jb) a[off(jb) + c0] = __builtin_fma(-a[off(jb) + k], l0, a[off(jb) + c0]);
+                    }
+                    if (c0 + 1 >= k + 2) {
+#pragma unroll
+                        for (int jb = cb; jb < RB; ++jb) a[off(jb) + c0 + 1] = __builtin_fma(-a[off(jb) + k], l1, a[off(jb) + c0 + 1]);
+                    }
+                }
+            }
+            inv = inv_next;
             if constexpr (LPS > 1) { if (k % LPS == LPS - 1) __builtin_amdgcn_sched_barrier(0); }
         }
         return ok;
@@ -221,22 +256,44 @@ struct Spec {
 #pragma unroll
         for (int jb = 0; jb < RB; ++jb) b[jb] *= invd[jb];
         // backward, column-oriented: after step k every row i < k has y_i -= l_ki x_k
+        if constexpr (LPS == 1) {
 #pragma unroll
-        for (int k = n - 1; k >= 0; --k) {
-            const int kb = k / LPS, kr = k % LPS;
-            const double xk = bcast_rt(b[kb] * invd[kb], kr);
+            for (int k = n - 1; k >= 0; --k) {
+                const double xk = b[k] * invd[k];
 #pragma unroll
-            for (int jb = 0; jb <= kb; ++jb) {
-                if constexpr (LPS == 1) {
-                    if (jb == kb) continue;
-                    b[jb] = __builtin_fma(-a[off(kb) + jb], xk, b[jb]);       // l_{k,jb} from my own row k
-                } else {
-                    // l_{k,i} for my column i = jb*LPS + r: mirror column i, row k (zero when i >= k)
-                    const double lki = lds[colstart_r(jb) + (kb - jb) * 64 + s * LPS + (kr ^ r)];
-                    b[jb] = __builtin_fma(-lki, xk, b[jb]);
-                }
+                for (int jb = 0; jb < k; ++jb) b[jb] = __builtin_fma(-a[off(k) + jb], xk, b[jb]);   // l_{k,jb} from my own row k
             }
-            if constexpr (LPS > 1) { if (k % LPS == 0) __builtin_amdgcn_sched_barrier(0); }
+        } else {
+            // l_{k,i} for my column i = jb*LPS + r sits in mirror column i, row k (zero when i >= k).  The
+            // entries a row-block of steps needs are fetched one block ahead of the dependent chain
+            // (double buffer), so the LDS latency is hidden behind the previous block's arithmetic.
+            double cur[LPS][RB], nxt[LPS][RB];
+#pragma unroll
+            for (int kr = 0; kr < LPS; ++kr)
+#pragma unroll
+                for (int jb = 0; jb < RB; ++jb) cur[kr][jb] = lds[colstart_r(jb) + (RB - 1 - jb) * 64 + s * LPS + (kr ^ r)];
+#pragma unroll
+            for (int kb = RB - 1; kb >= 0; --kb) {
+                if (kb > 0) {
+#pragma unroll
+                    for (int kr = 0; kr < LPS; ++kr)
+#pragma unroll
+                        for (int jb = 0; jb < kb; ++jb) nxt[kr][jb] = lds[colstart_r(jb) + (kb - 1 - jb) * 64 + s * LPS + (kr ^ r)];
+                }
+#pragma unroll
+                for (int kr = LPS - 1; kr >= 0; --kr) {
+                    const double xk = bcast_rt(b[kb] * invd[kb], kr);
+#pragma unroll
+                    for (int jb = 0; jb <= kb; ++jb) b[jb] = __builtin_fma(-cur[kr][jb], xk, b[jb]);
+                }
+                if (kb > 0) {
+#pragma unroll
+                    for (int kr = 0; kr < LPS; ++kr)
+#pragma unroll
+                        for (int jb = 0; jb < kb; ++jb) cur[kr][jb] = nxt[kr][jb];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #pragma unroll
         for (int jb = 0; jb < RB; ++jb) b[jb] *= invd[jb];
@@ -516,7 +573,10 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
     const long long Bsz = p.Bsz;
     const long long b_raw = (long long)blockIdx.x * SPW + s;
     const bool valid = b_raw < Bsz;
-    const long long b = valid ? b_raw : Bsz - 1;      // surplus groups recompute the last instance, never store
+    const long long slot = valid ? b_raw : Bsz - 1;   // surplus groups recompute the last slot, never store
+    // processing order: instances sorted by difficulty so that the 16 instances of a wave leave the
+    // constrained regime together and the longest waves are dispatched first
+    const long long b = p.perm ? (long long)p.perm[slot] : slot;
     const double *sh = p.sh;
 
     // ---------------- condensing ----------------
@@ -705,7 +765,7 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (p.presolve) {
+    if (p.presolve || MODE == MODE_PROBE) {
         // G = -P^-1 Fq (one column per state) and v_r = -P^-1 qr overwrite Fq and qr
 #pragma unroll
         for (int e = 0; e < S::TRI; ++e) st.a[e] = st.Pm.get(e);
@@ -777,7 +837,18 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
         return cost;
     };
 
-    if constexpr (MODE == MODE_SOLVE) {
+    if constexpr (MODE == MODE_PROBE) {
+        // difficulty key: how far the unconstrained minimiser at x0 sticks out of the box (<= 1: interior)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) st.x[i] = LD(p.x0, i);
+        double vu[RB];
+        st.linear_term(vu);
+        double rho = 0.0;
+#pragma unroll
+        for (int jb = 0; jb < RB; ++jb) rho = fmax(rho, fabs(vu[jb]) * frcp(st.hh(p, jb)));
+        rho = group_max<LPS>(rho);
+        if (writer) p.key[b] = (rho == rho) ? rho : 1e300;
+    } else if constexpr (MODE == MODE_SOLVE) {
         double x0[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) { x0[i] = LD(p.x0, i); st.x[i] = x0[i]; }
@@ -871,7 +942,7 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
         }
         if (writer) p.JT[b] = cost;
     }
-    if (writer) {
+    if (MODE != MODE_PROBE && writer) {
         if (p.status) p.status[b] = status;
         if (p.iters) p.iters[b] = iters;
     }
@@ -893,6 +964,8 @@ static void launch_one(const KParams &p, hipStream_t stream)
         hipLaunchKernelGGL((lqmpc_spec_kernel<NX, NU, N, LPS, MODE_SOLVE>), dim3(grid), dim3(64), 0, stream, p);
     else if (p.mode == MODE_MAXVN)
         hipLaunchKernelGGL((lqmpc_spec_kernel<NX, NU, N, LPS, MODE_MAXVN>), dim3(grid), dim3(64), 0, stream, p);
+    else if (p.mode == MODE_PROBE)
+        hipLaunchKernelGGL((lqmpc_spec_kernel<NX, NU, N, LPS, MODE_PROBE>), dim3(grid), dim3(64), 0, stream, p);
     else
         hipLaunchKernelGGL((lqmpc_spec_kernel<NX, NU, N, LPS, MODE_ROLLOUT>), dim3(grid), dim3(64), 0, stream, p);
 }

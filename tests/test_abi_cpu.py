@@ -28,8 +28,8 @@ def test_version_and_defaults():
     assert b"gfx950" in L.lqmpc_version()
     o = _lib.Options()
     L.lqmpc_default_options(ctypes.byref(o))
-    assert o.eps == 1e-12 and o.max_iter == 50 and o.polish == 1 and o.kernel == _lib.KERNEL_AUTO and o.presolve == -1
-    assert ctypes.sizeof(_lib.Options) == 40
+    assert o.eps == 1e-12 and o.max_iter == 50 and o.polish == 1 and o.kernel == _lib.KERNEL_AUTO and o.presolve == -1 and o.order == -1
+    assert ctypes.sizeof(_lib.Options) == 48
 
 
 def test_no_device_is_an_error_not_a_fallback():

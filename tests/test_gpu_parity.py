@@ -249,3 +249,27 @@ def test_data_generation_reproduces_reference_npz(solver, golden_dir):
     mv = orc.max_vn_batch(7, A, B, Q2, R1, Q2, [-0.1], [0.1], out["x0_vec"]).reshape(100, 10)
     assert rel(out["M_V_error"], mv) < TIGHT
     assert np.all(out["M_V_error"] / beh.epsilon_lqr > 4.0) and np.all(out["M_V_error"] / beh.epsilon_lqr < 5.0)
+
+
+def test_difficulty_ordering_is_transparent(solver, golden_dir):
+    """options.order = 1 (probe + radix sort, hardest first) must not change any instance's result."""
+    b = synth.make_batch(3, Bsz=4096 + 37)
+    try:
+        solver.set_options(order=0)
+        r0 = solver.rollout_batch(20, *args(b), b["x0"], b["A_true"], b["B_true"], want_traj=True)
+        solver.set_options(order=1)
+        r1 = solver.rollout_batch(20, *args(b), b["x0"], b["A_true"], b["B_true"], want_traj=True)
+        solver.set_options(order=1, presolve=0)
+        r2 = solver.rollout_batch(20, *args(b), b["x0"], b["A_true"], b["B_true"], want_traj=True)
+    finally:
+        solver.set_options(order=-1, presolve=-1)
+    for k in ("J_T", "X", "U"):
+        np.testing.assert_array_equal(r0[k], r1[k])          # same algorithm, different order: bit-identical
+    # without presolve the interior steps go through the interior-point loop instead: same answers to tolerance
+    assert rel(r0["J_T"], r2["J_T"]) < TIGHT and u_err(r0["U"], r2["U"]) < RTOL
+    np.testing.assert_array_equal(r0["iters"], r1["iters"])
+    assert np.all(r1["status"] == 0) and np.all(r2["status"] == 0)
+    idx = np.random.default_rng(1).choice(b["Bsz"], 512, replace=False)
+    sub = dict(b, A=np.ascontiguousarray(b["A"][:, :, idx]), B=np.ascontiguousarray(b["B"][:, :, idx]))
+    ref = orc.rollout_batch(20, *args(sub), np.ascontiguousarray(b["x0"][:, idx]), b["A_true"], b["B_true"])
+    assert rel(r1["J_T"][idx], ref["J_T"]) < TIGHT

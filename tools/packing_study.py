@@ -1,0 +1,26 @@
+"""Dev tool: how many wave-steps (16 systems in lockstep) need the interior-point loop under different instance orders."""
+import sys, numpy as np
+sys.path.insert(0, '.')
+from lq_mpc_amd import synth
+from oracle import oracle as orc
+Bsz, T = 4096, 30
+b = synth.make_batch(3, Bsz=Bsz)
+N = b['N']
+out = orc.rollout_batch(T, N, b['A'], b['B'], b['Q'], b['R'], b['P'], b['lb'], b['ub'], b['x0'], b['A_true'], b['B_true'], want_traj=True)
+X = out['X']
+con = np.zeros((T, Bsz), bool)
+rho = np.zeros(Bsz)
+for i in range(Bsz):
+    H, F = orc.condense(b['A'][:, :, i], b['B'][:, :, i], b['Q'], b['R'], b['P'], N)
+    G = -np.linalg.solve(H, F)            # v_unc = G x
+    V = G @ X[:, :T, i]                   # (n, T)
+    con[:, i] = (np.abs(V) > 0.1).any(axis=0)
+    rho[i] = np.abs(V[:, 0]).max() / 0.1
+print('constrained fraction of (step,system):', con.mean())
+def wave_frac(order):
+    c = con[:, order].reshape(T, Bsz // 16, 16)
+    return c.any(axis=2).mean(), c.any(axis=2).sum(axis=0)
+for name, order in (('natural', np.arange(Bsz)), ('sorted by rho(t=0)', np.argsort(-rho)), ('sorted by #constrained steps (ideal)', np.argsort(-con.sum(0), kind='stable')),
+                    ('sorted by |x0|', np.argsort(-np.linalg.norm(b['x0'], axis=0)))):
+    f, per_wave = wave_frac(order)
+    print(f'{name:40s}: wave-steps needing IPM {f:.3f}; per-wave IPM steps: max {per_wave.max()} mean {per_wave.mean():.1f}')
