@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (box share: 16 per GPU)")
     ap.add_argument("--no-oneshot", action="store_true", help="skip the extra one-shot measurement")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse the sharded path on one GPU)")
+    ap.add_argument("--all-on-gpu0", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -57,16 +60,21 @@ def main():
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     dist = None
+    if args.all_on_gpu0:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")     # where the collectives run
 
     cfg = synth.CONFIGS[args.config]
     nx, nu, N = cfg["nx"], cfg["nu"], cfg["N"]
@@ -111,7 +119,7 @@ def main():
             if ev is not None:
                 ev[1].record()
             if world > 1:
-                ld.all_gather_costs(dJT, world * Bsz)       # RCCL all-gather of the cost curve
+                ld.all_gather_costs(dJT.to(cdev), world * Bsz)   # RCCL all-gather of the cost curve
         for _ in range(warmup):
             one_step()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -126,7 +134,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         kernel_ms = float(np.mean([a.elapsed_time(bb) for a, bb in evs]))
@@ -140,7 +148,7 @@ def main():
     iters_total = float(dit.double().sum().item())
     iters_mean = iters_total / qp_per_launch
     if world > 1:
-        agg = torch.tensor([iters_total, float(status_bad)], dtype=torch.float64, device=dev)
+        agg = torch.tensor([iters_total, float(status_bad)], dtype=torch.float64, device=cdev)
         dist.all_reduce(agg)
         iters_mean = float(agg[0].item()) / (world * qp_per_launch)
         status_bad = int(agg[1].item())
