@@ -47,7 +47,7 @@ struct lqmpc_handle {
     bool own_stream = false;
     lqmpc_options opt;
     DevBuf shared, ws;
-    DevBuf key, key_sorted, idx, perm, cub_tmp;   // difficulty ordering of rollout batches
+    DevBuf key, key_sorted, idx, perm, cub_tmp, rec;   // difficulty ordering of rollout batches
     DevBuf stage[12];                // host-flavour staging (inputs and outputs)
     std::vector<double> shared_host; // last uploaded shared block
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -134,7 +134,7 @@ int lqmpc_destroy(lqmpc_handle *h)
     (void)hipStreamSynchronize(h->stream);
     if (h->shared.p) (void)hipFree(h->shared.p);
     if (h->ws.p) (void)hipFree(h->ws.p);
-    for (DevBuf *b : {&h->key, &h->key_sorted, &h->idx, &h->perm, &h->cub_tmp}) if (b->p) (void)hipFree(b->p);
+    for (DevBuf *b : {&h->key, &h->key_sorted, &h->idx, &h->perm, &h->cub_tmp, &h->rec}) if (b->p) (void)hipFree(b->p);
     for (auto &b : h->stage) if (b.p) (void)hipFree(b.p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -276,6 +276,8 @@ static int build_order(lqmpc_handle *h, KParams &p)
     if (!rc) rc = ensure(h, h->key_sorted, B * sizeof(double));
     if (!rc) rc = ensure(h, h->idx, B * sizeof(int));
     if (!rc) rc = ensure(h, h->perm, B * sizeof(int));
+    const size_t rec_doubles = (size_t)(p.nx * p.nx + p.nx * p.nu + p.nx);
+    if (!rc) rc = ensure(h, h->rec, B * rec_doubles * sizeof(double));
     if (rc) return rc;
     size_t tmp_bytes = 0;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, (const double *)h->key.p, (double *)h->key_sorted.p,
@@ -286,12 +288,14 @@ static int build_order(lqmpc_handle *h, KParams &p)
     q.mode = lqmpc::MODE_PROBE;
     q.perm = nullptr;
     q.key = (double *)h->key.p;
+    q.stage = (double *)h->rec.p;
     const char *name = nullptr;
     if (!lqmpc::launch_spec(q, h->stream, &name)) return fail(LQMPC_ERR_UNSUPPORTED, "probe launch failed");
     hipLaunchKernelGGL(lqmpc_iota_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, (int *)h->idx.p, (int)B);
     HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(h->cub_tmp.p, tmp_bytes, (const double *)h->key.p, (double *)h->key_sorted.p,
                                                          (const int *)h->idx.p, (int *)h->perm.p, (int)B, 0, 64, h->stream));
     p.perm = (const int *)h->perm.p;
+    p.rec = (const double *)h->rec.p;
     return 0;
 }
 

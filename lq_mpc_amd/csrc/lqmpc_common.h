@@ -31,6 +31,8 @@ struct KParams {
     int *status, *iters;                  // may be null
     const int *perm;                      // processing order (slot -> instance), null = natural order
     double *key;                          // MODE_PROBE output: difficulty key per instance
+    double *stage;                        // MODE_PROBE output: instance-major [A|B|x0] records (null: none)
+    const double *rec;                    // input records staged by the probe (null: read A, B, x0 directly)
 };
 
 // ---- fp64 reciprocal / reciprocal square root: hardware seed + Newton steps ----

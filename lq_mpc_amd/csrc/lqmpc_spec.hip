@@ -135,20 +135,20 @@ struct Spec {
     double sl[RB], su[RB], zl[RB], zu[RB], rd[RB];   // interior-point state; v = sl - h is implied
     double v[RB];          // result of the last QP (shifted inputs), set at the end of solve_qp
     double x[NX];          // current state (replicated in the group)
-    AccArr<2> hc;          // half-width / centre of own rows' input (LPS > 1: same input for all own rows)
     int r, s, lane;        // sub-lane in group, group in wave, lane in wave
     double *lds;
 
     // half-width and centre of own row jb
     __device__ __forceinline__ double hh(const KParams &p, int jb) const
     {
-        if constexpr (LPS == 1) { const int k = jb % NU; return 0.5 * (p.sh[p.so.ub + k] - p.sh[p.so.lb + k]); }
-        else return hc.get(0);
+        // LPS > 1: all own rows belong to input r % NU (LPS is a multiple of NU); two cached loads, no register kept
+        const int k = (LPS == 1) ? jb % NU : r % NU;
+        return 0.5 * (p.sh[p.so.ub + k] - p.sh[p.so.lb + k]);
     }
     __device__ __forceinline__ double cc(const KParams &p, int jb) const
     {
-        if constexpr (LPS == 1) { const int k = jb % NU; return 0.5 * (p.sh[p.so.ub + k] + p.sh[p.so.lb + k]); }
-        else return hc.get(1);
+        const int k = (LPS == 1) ? jb % NU : r % NU;
+        return 0.5 * (p.sh[p.so.ub + k] + p.sh[p.so.lb + k]);
     }
 
     // ---- in-place Cholesky of the row-distributed matrix in a[] (right-looking, column k) ----
@@ -558,12 +558,19 @@ struct Spec {
 
 // A, B entry of instance b (instance-minor)
 #define LD(ptr, e) (ptr)[(long long)(e) * Bsz + b]
+// A, B, x0 of instance b: from the caller's instance-minor arrays, or -- when the batch is walked in
+// sorted order -- from the instance-major record [A | B | x0] the probe launch staged (contiguous per
+// instance, so the permuted reads use whole sectors)
+#define LDA(e) (p.rec ? p.rec[b * REC + (e)] : LD(p.A, e))
+#define LDB(e) (p.rec ? p.rec[b * REC + NX * NX + (e)] : LD(p.B, e))
+#define LDX(e) (p.rec ? p.rec[b * REC + NX * NX + NX * NU + (e)] : LD(p.x0, e))
 
 template <int NX, int NU, int N, int LPS, int MODE>
 __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
 {
     using S = Spec<NX, NU, N, LPS>;
     constexpr int n = S::n, RB = S::RB, SPW = S::SPW;
+    constexpr int REC = NX * NX + NX * NU + NX;      // doubles per staged instance record
     __shared__ double lds[S::LDS_DOUBLES];
     S st;
     st.lds = lds;
@@ -584,19 +591,14 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
     // M lives in LDS ([m][input][state][instance]); a lane fetches the Gamma column of ITS row with a
     // lane-dependent address and the columns of the other side with group-uniform addresses, so
     // no A^m B table is held in registers.
-    if constexpr (LPS > 1) {
-        const int k0 = r % NU;
-        st.hc.set(0, 0.5 * (sh[p.so.ub + k0] - sh[p.so.lb + k0]));
-        st.hc.set(1, 0.5 * (sh[p.so.ub + k0] + sh[p.so.lb + k0]));
-    }
     {
         double A[NX][NX], Bm[NX][NU];
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) A[i][j] = LD(p.A, i * NX + j);
+            for (int j = 0; j < NX; ++j) A[i][j] = LDA(i * NX + j);
 #pragma unroll
-            for (int k = 0; k < NU; ++k) Bm[i][k] = LD(p.B, i * NU + k);
+            for (int k = 0; k < NU; ++k) Bm[i][k] = LDB(i * NU + k);
         }
         // stage M[m][k][i] at lds[((m*NU + k)*NX + i)*SPW + s]; every lane of a group computes the same
         // chain, sub-lane (e % LPS) stores element e
@@ -795,9 +797,9 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) A[i][j] = LD(p.A, i * NX + j);
+            for (int j = 0; j < NX; ++j) A[i][j] = LDA(i * NX + j);
 #pragma unroll
-            for (int k = 0; k < NU; ++k) Bm[i][k] = LD(p.B, i * NU + k);
+            for (int k = 0; k < NU; ++k) Bm[i][k] = LDB(i * NU + k);
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -840,7 +842,7 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
     if constexpr (MODE == MODE_PROBE) {
         // difficulty key: how far the unconstrained minimiser at x0 sticks out of the box (<= 1: interior)
 #pragma unroll
-        for (int i = 0; i < NX; ++i) st.x[i] = LD(p.x0, i);
+        for (int i = 0; i < NX; ++i) st.x[i] = LDX(i);
         double vu[RB];
         st.linear_term(vu);
         double rho = 0.0;
@@ -848,10 +850,18 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
         for (int jb = 0; jb < RB; ++jb) rho = fmax(rho, fabs(vu[jb]) * frcp(st.hh(p, jb)));
         rho = group_max<LPS>(rho);
         if (writer) p.key[b] = (rho == rho) ? rho : 1e300;
+        if (p.stage && valid) {
+            // instance-major copy of the inputs for the sorted walk (each lane of the group stores a quarter)
+#pragma unroll
+            for (int e = 0; e < REC; ++e) {
+                const double val = e < NX * NX ? LD(p.A, e) : (e < NX * NX + NX * NU ? LD(p.B, e - NX * NX) : LD(p.x0, e - NX * NX - NX * NU));
+                if (LPS == 1 || e % LPS == r) p.stage[b * REC + e] = val;
+            }
+        }
     } else if constexpr (MODE == MODE_SOLVE) {
         double x0[NX];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { x0[i] = LD(p.x0, i); st.x[i] = x0[i]; }
+        for (int i = 0; i < NX; ++i) { x0[i] = LDX(i); st.x[i] = x0[i]; }
         status = st.solve_qp(p, iters);
         const double vn = value_fn(x0);
         double u0[NU];
@@ -877,7 +887,7 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
     } else {
         double cost = 0.0;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) st.x[i] = LD(p.x0, i);
+        for (int i = 0; i < NX; ++i) st.x[i] = LDX(i);
 #pragma unroll
         for (int i = 0; i < NX; ++i)
 #pragma unroll
