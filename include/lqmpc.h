@@ -37,7 +37,8 @@
  *
  * Errors: every call returns 0 on success or a negative lqmpc_error; nothing is thrown
  * across the ABI.  lqmpc_last_error() gives a thread-local message.  Per instance,
- * status[b] is 0 converged, 1 iteration cap reached, 2 non-finite data.  The QP is always
+ * status[b] is 0 converged, 1 iteration cap reached, 2 non-finite data; iters[b] counts the KKT-system
+ * factorisations spent on instance b (interior-point iterations + active-set iterations).  The QP is always
  * feasible and strictly convex (R > 0, non-empty box), so "infeasible" cannot occur.
  *
  * Threading: a handle is bound to one device and one stream and is not thread-safe;
@@ -80,14 +81,17 @@ typedef struct lqmpc_options {
     int32_t kernel;    /* enum lqmpc_kernel (default AUTO) */
     int32_t presolve;  /* unconstrained-minimiser shortcut: the minimiser v = G x + v_r (G = -P^-1 Fq, built once
                           per instance) is tested against the box before any iteration; a QP whose minimiser is
-                          interior is finished there, exactly.  -1 auto (on for rollouts, off for one-shot calls),
-                          0 off, 1 on.  Specialised kernels only; the generic kernel ignores it.  (default -1) */
+                          interior is finished there, exactly.  -1 auto (= on), 0 off, 1 on.  Specialised kernels only; the generic kernel ignores it.  (default -1) */
     int32_t order;     /* processing order of a rollout batch.  1: a probe launch computes per instance how far the
                           unconstrained minimiser at x0 leaves the box, the batch is radix-sorted by that key and the
                           rollout walks it hardest-first, so the instances that share a wavefront leave the constrained
                           regime together (results are written back to their original positions).  0: natural order.
                           -1 auto (1 for specialised rollouts with presolve, T >= 4 and Bsz >= 1024).  (default -1) */
-    int32_t reserved;
+    int32_t warm_start; /* primal-dual active-set warm start: before the interior-point loop, the QP is solved exactly on
+                          the face guessed from the unconstrained minimiser (rows outside the box sit on their bound)
+                          and the guess is corrected from the KKT signs, up to 8 times; a fixed point is the exact
+                          optimum, otherwise the interior-point loop runs.  -1 auto (= presolve), 0 off, 1 on.
+                          Specialised kernels only.  (default -1) */
 } lqmpc_options;
 
 /* Limits of this build. */

@@ -92,7 +92,7 @@ void lqmpc_default_options(lqmpc_options *opt)
     opt->kernel = LQMPC_KERNEL_AUTO;
     opt->presolve = -1;
     opt->order = -1;
-    opt->reserved = 0;
+    opt->warm_start = -1;
 }
 
 int lqmpc_create_on_stream(int device, void *hip_stream, lqmpc_handle **out)
@@ -160,6 +160,7 @@ int lqmpc_set_options(lqmpc_handle *h, const lqmpc_options *opt)
     if (opt->kernel < LQMPC_KERNEL_AUTO || opt->kernel > LQMPC_KERNEL_SPECIALIZED) return fail(LQMPC_ERR_BAD_ARG, "unknown kernel selector");
     if (opt->presolve < -1 || opt->presolve > 1) return fail(LQMPC_ERR_BAD_ARG, "presolve must be -1, 0 or 1");
     if (opt->order < -1 || opt->order > 1) return fail(LQMPC_ERR_BAD_ARG, "order must be -1, 0 or 1");
+    if (opt->warm_start < -1 || opt->warm_start > 1) return fail(LQMPC_ERR_BAD_ARG, "warm_start must be -1, 0 or 1");
     h->opt = *opt;
     return 0;
 }
@@ -243,8 +244,9 @@ static int prepare(lqmpc_handle *h, const Call &c, KParams &p)
     p.T = c.T; p.K = c.K; p.mode = c.mode;
     p.true_per_instance = c.true_per_instance;
     p.has_ref = (c.x_ref || c.u_ref) ? 1 : 0;
-    p.max_iter = h->opt.max_iter; p.polish = h->opt.polish;
-    p.presolve = h->opt.presolve < 0 ? (c.mode == lqmpc::MODE_ROLLOUT ? 1 : 0) : h->opt.presolve;
+    p.max_iter = h->opt.max_iter; p.polish = h->opt.polish; p.key_mode = 0;
+    p.presolve = h->opt.presolve < 0 ? 1 : h->opt.presolve;
+    p.warm_start = h->opt.warm_start < 0 ? p.presolve : h->opt.warm_start;
     p.eps = h->opt.eps; p.tau = h->opt.tau; p.z0_scale = h->opt.z0_scale;
     p.Bsz = c.Bsz;
     p.sh = (const double *)h->shared.p;

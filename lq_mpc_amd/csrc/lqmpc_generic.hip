@@ -289,6 +289,7 @@ __device__ static int solve_qp(const Ctx &c, int *iters)
     *iters += it;
     if (status == 2) return 2;
     if (p.polish) {
+        *iters += 1;     // the polish is one more factorisation
         // exact solve on the identified active set; accepted only if it satisfies the KKT conditions
         for (int i = 0; i < n; ++i) {
             const int k = i % nu; const double h = 0.5 * (ub[k] - lb[k]);

@@ -338,50 +338,107 @@ struct Spec {
         }
     }
 
-    // ---- one box QP at state x: Mehrotra predictor-corrector + polish; result in v[] ----
-    __device__ __forceinline__ int solve_qp(const KParams &p, int &iters)
+    // ---- primal-dual active-set iterations ----
+    // One iteration solves the QP restricted to the face given by the sets (rows in myL / myU sit on their
+    // lower / upper bound, the others solve P_FF v_F = -(q_F + P_FA v_A)) and re-derives the sets from the
+    // KKT signs: a free row outside the box becomes active, an active row whose multiplier has the wrong
+    // sign is released.  A fixed point satisfies every KKT condition, i.e. it is the exact optimum; it is
+    // committed to v[] only then.  Serves as warm start (sets guessed from the unconstrained minimiser)
+    // and as polish (sets read off the interior-point iterate).  Groups with run == false are untouched.
+    __device__ __forceinline__ bool pdas(const KParams &p, unsigned &myL, unsigned &myU, bool run, int maxit, double gtol, int &nfact)
     {
-        double q[RB];
-        linear_term(q);
-        bool inside = false;
-        if (p.presolve) {
-            // LDS holds G = -P^-1 Fq and qr holds v_r: q is the unconstrained minimiser v_unc = G x + v_r.
-            unsigned in = 1u;
+        bool conv = !run, dead = false;
+        for (int k = 0; k < maxit; ++k) {
+            if (!__any(!conv && !dead)) break;
+            const unsigned colmask = group_or<LPS>(myL | myU);
+            double rhs[RB];
 #pragma unroll
             for (int jb = 0; jb < RB; ++jb) {
-                v[jb] = q[jb];
-                if (!(fabs(q[jb]) <= hh(p, jb))) in = 0u;
+                const unsigned bit = 1u << (jb * LPS + r_or0());
+                const double h = hh(p, jb);
+                rhs[jb] = (myL & bit) ? -h : ((myU & bit) ? h : 0.0);
             }
-            in = group_and<LPS>(in);
-            inside = in != 0u;
-            if (!__any(!inside)) return 0;           // every instance of the wave is done, exactly
-            double y[RB];
-            symv(q, y);                              // q = -P v_unc for the instances that must iterate
-#pragma unroll
-            for (int jb = 0; jb < RB; ++jb) q[jb] = -y[jb];
             __builtin_amdgcn_sched_barrier(0);
+            if (__any(colmask != 0)) {
+                double pd[RB];
+                symv(rhs, pd);
+#pragma unroll
+                for (int jb = 0; jb < RB; ++jb)
+                    if (!((myL | myU) & (1u << (jb * LPS + r_or0())))) rhs[jb] = -(qs.get(jb) + pd[jb]);
+            } else {
+#pragma unroll
+                for (int jb = 0; jb < RB; ++jb) rhs[jb] = -qs.get(jb);
+            }
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) {
+                const bool ai = (myL | myU) & (1u << (jb * LPS + r_or0()));
+#pragma unroll
+                for (int j = 0; j < rowlen(jb); ++j) {
+                    const bool diag = (LPS == 1) ? (j == jb) : (j - jb * LPS == r);
+                    const bool aj = (colmask >> j) & 1u;
+                    const double pv = Pm.get(off(jb) + j);     // read unconditionally: no branch per element
+                    a[off(jb) + j] = (ai || aj) ? (diag ? 1.0 : 0.0) : pv;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const bool ok = chol();
+            __builtin_amdgcn_sched_barrier(0);
+            solve(rhs);
+            __builtin_amdgcn_sched_barrier(0);
+            double g[RB];
+            if (__any(colmask != 0)) symv(rhs, g);      // gradient P v + q on the active rows (zero on the free ones)
+            else {
+#pragma unroll
+                for (int jb = 0; jb < RB; ++jb) g[jb] = -qs.get(jb);
+            }
+            unsigned nl = 0u, nu = 0u, fin = ok ? 1u : 0u;
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) {
+                const unsigned bit = 1u << (jb * LPS + r_or0());
+                const double h = hh(p, jb), vi = rhs[jb], gi = g[jb] + qs.get(jb);
+                const bool isL = myL & bit, isU = myU & bit;
+                const bool toL = isL ? (gi >= -gtol) : (!isU && vi < -h * (1.0 + 1e-12));
+                const bool toU = isU ? (gi <= gtol) : (!isL && vi > h * (1.0 + 1e-12));
+                if (toL) nl |= bit;
+                if (toU) nu |= bit;
+                if (!(fabs(vi) < 1e300)) fin = 0u;
+            }
+            const bool changed = group_or<LPS>((nl ^ myL) | (nu ^ myU)) != 0u;
+            fin = group_and<LPS>(fin);
+            if (!conv && !dead) {
+                nfact += 1;
+                if (!fin) dead = true;
+                else {
+                    myL = nl; myU = nu;
+                    if (!changed) {
+                        conv = true;
+#pragma unroll
+                        for (int jb = 0; jb < RB; ++jb) v[jb] = rhs[jb];
+                    }
+                }
+            }
         }
-#pragma unroll
-        for (int jb = 0; jb < RB; ++jb) qs.set(jb, q[jb]);
-        double scale = 0.0;
-#pragma unroll
-        for (int jb = 0; jb < RB; ++jb) scale = fmax(scale, fabs(q[jb]));
-        scale = group_max<LPS>(scale);
-        const bool finite_in = scale < 1e300;
-        scale = fmax(scale, 1e-100);
+        return conv;
+    }
+
+    // ---- Mehrotra predictor-corrector interior point on min 1/2 v'Pv + qs'v, |v| <= h ----
+    // Groups with run == false are frozen (their state is initialised but never stepped).  Leaves the
+    // iterate in sl, su, zl, zu; returns 0 converged, 1 iteration cap, 2 non-finite.
+    __device__ __forceinline__ int ipm(const KParams &p, bool run, double scale, int &iters)
+    {
         const double z0 = p.z0_scale * scale;
         double hmin = 1e300;
 #pragma unroll
         for (int jb = 0; jb < RB; ++jb) {
             const double h = hh(p, jb);
             hmin = fmin(hmin, h);
-            sl[jb] = h; su[jb] = h; zl[jb] = z0; zu[jb] = z0; rd[jb] = q[jb];
+            sl[jb] = h; su[jb] = h; zl[jb] = z0; zu[jb] = z0; rd[jb] = qs.get(jb);
         }
         hmin = group_max<LPS>(-hmin); hmin = -hmin;
         const double inv2n = 1.0 / (2.0 * n);
         const double mu_tol = p.eps * scale * hmin, rd_tol = p.eps * scale;
-        int status = inside ? 0 : (finite_in ? 1 : 2);
-        bool live = finite_in && !inside; // this group still iterates
+        int status = 1;
+        bool live = run;                  // this group still iterates
         int it = 0;
         for (; it < p.max_iter; ++it) {
             double mu = 0.0, rn = 0.0;
@@ -473,74 +530,83 @@ struct Spec {
                 rd[jb] = __builtin_fma(1.0 - ap, rd[jb], (ap - ad) * (dzl[jb] - dzu[jb]));
             }
         }
-        if (status == 2) {
-#pragma unroll
-            for (int jb = 0; jb < RB; ++jb) sl[jb] = hh(p, jb);      // v = 0 below
-        }
-        bool polished = false;
-        if (p.polish) {
-            // exact solve on the identified active face: rows with z > s sit on their bound (v = -h or +h),
-            // the others solve P_FF v_F = -(q_F + P_FA v_A).  Solving for v itself (not for a correction)
-            // keeps full relative precision when the optimum is tiny compared with the box.
-            double rhs[RB];
-            unsigned mybits = 0;
+        return status;
+    }
+
+    // ---- one box QP at state x; the result goes to v[] ----
+    // 1. presolve: unconstrained minimiser inside the box -> done.  2. warm start: primal-dual active-set
+    // iterations from the rows where that minimiser leaves the box.  3. fallback: interior point, then the
+    // same active-set iterations as polish.  Every path ends in a verified KKT point (or, if the polish
+    // does not settle, in the interior-point iterate).
+    __device__ __forceinline__ int solve_qp(const KParams &p, int &iters)
+    {
+        double q[RB];
+        linear_term(q);
+        bool inside = false;
+        unsigned myL = 0u, myU = 0u;
+        if (p.presolve) {
+            // LDS holds G = -P^-1 Fq and qr holds v_r: q is the unconstrained minimiser v_unc = G x + v_r.
+            unsigned in = 1u;
 #pragma unroll
             for (int jb = 0; jb < RB; ++jb) {
-                const bool lo = zl[jb] > sl[jb], up = (!lo) && (zu[jb] > su[jb]);
+                const unsigned bit = 1u << (jb * LPS + r_or0());
                 const double h = hh(p, jb);
-                rhs[jb] = lo ? -h : (up ? h : 0.0);
-                if (lo || up) mybits |= 1u << (jb * LPS + r_or0());
+                v[jb] = q[jb];
+                if (!(fabs(q[jb]) <= h)) in = 0u;
+                if (q[jb] < -h) myL |= bit;
+                if (q[jb] > h) myU |= bit;
             }
-            const unsigned colmask = group_or<LPS>(mybits);
+            in = group_and<LPS>(in);
+            inside = in != 0u;
+            if (!__any(!inside)) return 0;           // every instance of the wave is done, exactly
+            double y[RB];
+            symv(q, y);                              // q = -P v_unc for the instances that must iterate
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) q[jb] = -y[jb];
             __builtin_amdgcn_sched_barrier(0);
-            {
-                double q[RB];
+        }
 #pragma unroll
-                for (int jb = 0; jb < RB; ++jb) q[jb] = qs.get(jb);
-                if (__any(colmask != 0)) {
-                    double pd[RB];
-                    symv(rhs, pd);
+        for (int jb = 0; jb < RB; ++jb) qs.set(jb, q[jb]);
+        double scale = 0.0;
 #pragma unroll
-                    for (int jb = 0; jb < RB; ++jb)
-                        if (!((mybits >> (jb * LPS + r_or0())) & 1u)) rhs[jb] = -(q[jb] + pd[jb]);
+        for (int jb = 0; jb < RB; ++jb) scale = fmax(scale, fabs(q[jb]));
+        scale = group_max<LPS>(scale);
+        const bool finite_in = scale < 1e300;
+        scale = fmax(scale, 1e-100);
+        const double gtol = 1e-10 * scale;
+        bool todo = finite_in && !inside;            // this group still needs a solution
+        int status = finite_in ? 0 : 2;
+        if (!finite_in) {
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) v[jb] = 0.0;
+        }
+        if (p.warm_start) {
+            if (pdas(p, myL, myU, todo, 8, gtol, iters)) todo = false;
+        }
+        if (__any(todo)) {
+            const int st = ipm(p, todo, scale, iters);
+            if (todo) {
+                status = st;
+                if (st == 2) {
+#pragma unroll
+                    for (int jb = 0; jb < RB; ++jb) v[jb] = 0.0;
                 } else {
 #pragma unroll
-                    for (int jb = 0; jb < RB; ++jb) rhs[jb] = -q[jb];
+                    for (int jb = 0; jb < RB; ++jb) v[jb] = sl[jb] - hh(p, jb);      // interior-point answer
                 }
             }
+            if (p.polish) {
+                unsigned pl = 0u, pu = 0u;
 #pragma unroll
-            for (int jb = 0; jb < RB; ++jb) {
-                const bool ai = (mybits >> (jb * LPS + r_or0())) & 1u;
-#pragma unroll
-                for (int j = 0; j < rowlen(jb); ++j) {
-                    const bool diag = (LPS == 1) ? (j == jb) : (j - jb * LPS == r);
-                    const bool aj = (colmask >> j) & 1u;
-                    const double pv = Pm.get(off(jb) + j);     // read unconditionally: no branch per element
-                    a[off(jb) + j] = (ai || aj) ? (diag ? 1.0 : 0.0) : pv;
+                for (int jb = 0; jb < RB; ++jb) {
+                    const unsigned bit = 1u << (jb * LPS + r_or0());
+                    const bool lo = zl[jb] > sl[jb], up = (!lo) && (zu[jb] > su[jb]);
+                    if (lo) pl |= bit;
+                    if (up) pu |= bit;
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const bool ok = chol();
-            __builtin_amdgcn_sched_barrier(0);
-            solve(rhs);
-            unsigned good = ok ? 1u : 0u;
-#pragma unroll
-            for (int jb = 0; jb < RB; ++jb) {
-                const bool ai = (mybits >> (jb * LPS + r_or0())) & 1u;
-                if (!ai && !(fabs(rhs[jb]) <= hh(p, jb) * (1.0 + 1e-12))) good = 0u;
-            }
-            good = group_and<LPS>(good);
-            polished = good != 0u && status != 2;
-            if (polished) {
-#pragma unroll
-                for (int jb = 0; jb < RB; ++jb) v[jb] = rhs[jb];
+                if (pdas(p, pl, pu, todo && st != 2, 3, gtol, iters) && todo && st != 2) status = 0;
             }
         }
-        if (!polished) {
-#pragma unroll
-            for (int jb = 0; jb < RB; ++jb) v[jb] = sl[jb] - hh(p, jb);
-        }
-        if (inside) linear_term(v);                  // presolve: this instance's answer is its v_unc
         return status;
     }
 
@@ -840,16 +906,37 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
     };
 
     if constexpr (MODE == MODE_PROBE) {
-        // difficulty key: how far the unconstrained minimiser at x0 sticks out of the box (<= 1: interior)
+        // difficulty key: the number of steps at which the unconstrained minimiser leaves the box when the
+        // plant is driven by the CLIPPED unconstrained law u = clip(first inputs of G x + v_r) -- a cheap
+        // stand-in for the real closed loop (no QP is solved) -- with the overshoot at x0 as tie-breaker
 #pragma unroll
-        for (int i = 0; i < NX; ++i) st.x[i] = LDX(i);
-        double vu[RB];
-        st.linear_term(vu);
-        double rho = 0.0;
+        for (int i = 0; i < NX; ++i) st.x[i] = LD(p.x0, i);
+        double rho = 0.0, cnt = 0.0;
+        for (int t = 0; t < (p.key_mode == 0 ? 1 : p.T); ++t) {
+            st.linear_term(st.v);
+            double rt = 0.0;
 #pragma unroll
-        for (int jb = 0; jb < RB; ++jb) rho = fmax(rho, fabs(vu[jb]) * frcp(st.hh(p, jb)));
-        rho = group_max<LPS>(rho);
-        if (writer) p.key[b] = (rho == rho) ? rho : 1e300;
+            for (int jb = 0; jb < RB; ++jb) rt = fmax(rt, fabs(st.v[jb]) * frcp(st.hh(p, jb)));
+            rt = group_max<LPS>(rt);
+            if (t == 0) rho = rt;
+            cnt += (rt > 1.0) ? 1.0 : 0.0;
+            double u[NU], xn[NX];
+#pragma unroll
+            for (int k = 0; k < NU; ++k) u[k] = st.u_at(p, k);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < NX; ++j) acc = __builtin_fma(p.true_per_instance ? LD(p.At, i * NX + j) : sh[p.so.At + i * NX + j], st.x[j], acc);
+#pragma unroll
+                for (int k = 0; k < NU; ++k) acc = __builtin_fma(p.true_per_instance ? LD(p.Bt, i * NU + k) : sh[p.so.Bt + i * NU + k], u[k], acc);
+                xn[i] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) st.x[i] = xn[i];
+        }
+        rho = (rho == rho) ? (p.key_mode == 0 ? rho : cnt + 1e-3 * fmin(rho, 900.0)) : 1e300;
+        if (writer) p.key[b] = rho;
         if (p.stage && valid) {
             // instance-major copy of the inputs for the sorted walk (each lane of the group stores a quarter)
 #pragma unroll

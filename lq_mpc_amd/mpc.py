@@ -97,7 +97,7 @@ class BatchSolver:
     def get_options(self):
         o = _lib.Options()
         _lib.check(self._L.lqmpc_get_options(self._h, ctypes.byref(o)))
-        return {k: getattr(o, k) for k, _ in o._fields_ if k != "reserved"}
+        return {k: getattr(o, k) for k, _ in o._fields_}
 
     def set_options(self, **kw):
         o = _lib.Options()

@@ -28,7 +28,7 @@ def test_version_and_defaults():
     assert b"gfx950" in L.lqmpc_version()
     o = _lib.Options()
     L.lqmpc_default_options(ctypes.byref(o))
-    assert o.eps == 1e-12 and o.max_iter == 50 and o.polish == 1 and o.kernel == _lib.KERNEL_AUTO and o.presolve == -1 and o.order == -1
+    assert o.eps == 1e-12 and o.max_iter == 50 and o.polish == 1 and o.kernel == _lib.KERNEL_AUTO and o.presolve == -1 and o.order == -1 and o.warm_start == -1
     assert ctypes.sizeof(_lib.Options) == 48
 
 

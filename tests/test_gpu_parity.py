@@ -211,7 +211,7 @@ def test_presolve_and_polish_options_agree(solver, cfg, golden_dir):
     r1 = orc.solve_batch(*args(b), b["x0"])
     try:
         for presolve in (0, 1):
-            solver.set_options(presolve=presolve, polish=1)
+            solver.set_options(presolve=presolve, polish=1, warm_start=0)
             got = solver.rollout_batch(20, *args(b), b["x0"], b["A_true"], b["B_true"], want_traj=True)
             assert np.all(got["status"] == 0)
             assert rel(got["J_T"], ref["J_T"]) < TIGHT and u_err(got["U"], ref["U"]) < RTOL
@@ -221,11 +221,18 @@ def test_presolve_and_polish_options_agree(solver, cfg, golden_dir):
                 assert got["iters"].sum() < iters_off.sum()       # interior steps cost no iterations
             else:
                 iters_off = got["iters"]
-        solver.set_options(presolve=-1, polish=0, eps=1e-13)       # interior point only: still inside RTOL
+        solver.set_options(presolve=-1, polish=0, eps=1e-13, warm_start=0)       # interior point only: still inside RTOL
         got = solver.rollout_batch(20, *args(b), b["x0"], b["A_true"], b["B_true"], want_traj=True)
         assert rel(got["J_T"], ref["J_T"]) < RTOL and u_err(got["U"], ref["U"]) < RTOL
+        for presolve in (0, 1):                                    # active-set warm start with / without presolve
+            solver.set_options(presolve=presolve, polish=1, eps=1e-12, warm_start=1)
+            got = solver.rollout_batch(20, *args(b), b["x0"], b["A_true"], b["B_true"], want_traj=True)
+            assert np.all(got["status"] == 0)
+            assert rel(got["J_T"], ref["J_T"]) < TIGHT and u_err(got["U"], ref["U"]) < RTOL
+            g1 = solver.solve_batch(*args(b), b["x0"])
+            assert rel(g1["V_N"], r1["V_N"]) < TIGHT and u_err(g1["u_0"], r1["u_0"]) < RTOL
     finally:
-        solver.set_options(presolve=-1, polish=1, eps=1e-12)
+        solver.set_options(presolve=-1, polish=1, eps=1e-12, warm_start=-1)
 
 
 # ---------------- the batch caller: data_generation's hot half ----------------
@@ -259,10 +266,10 @@ def test_difficulty_ordering_is_transparent(solver, golden_dir):
         r0 = solver.rollout_batch(20, *args(b), b["x0"], b["A_true"], b["B_true"], want_traj=True)
         solver.set_options(order=1)
         r1 = solver.rollout_batch(20, *args(b), b["x0"], b["A_true"], b["B_true"], want_traj=True)
-        solver.set_options(order=1, presolve=0)
+        solver.set_options(order=1, presolve=0, warm_start=0)
         r2 = solver.rollout_batch(20, *args(b), b["x0"], b["A_true"], b["B_true"], want_traj=True)
     finally:
-        solver.set_options(order=-1, presolve=-1)
+        solver.set_options(order=-1, presolve=-1, warm_start=-1)
     for k in ("J_T", "X", "U"):
         np.testing.assert_array_equal(r0[k], r1[k])          # same algorithm, different order: bit-identical
     # without presolve the interior steps go through the interior-point loop instead: same answers to tolerance

@@ -24,3 +24,25 @@ for name, order in (('natural', np.arange(Bsz)), ('sorted by rho(t=0)', np.argso
                     ('sorted by |x0|', np.argsort(-np.linalg.norm(b['x0'], axis=0)))):
     f, per_wave = wave_frac(order)
     print(f'{name:40s}: wave-steps needing IPM {f:.3f}; per-wave IPM steps: max {per_wave.max()} mean {per_wave.mean():.1f}')
+
+# ---- better keys: simulate the clipped unconstrained law and count predicted constrained steps ----
+def predicted(clip):
+    cnt = np.zeros(Bsz); first = np.zeros(Bsz); area = np.zeros(Bsz)
+    for i in range(Bsz):
+        H, F = orc.condense(b['A'][:, :, i], b['B'][:, :, i], b['Q'], b['R'], b['P'], N)
+        G = -np.linalg.solve(H, F)
+        x = b['x0'][:, i].copy(); c = 0; a = 0.0
+        for t in range(T):
+            v = G @ x
+            rho_t = np.abs(v).max() / 0.1
+            if rho_t > 1: c += 1; a += rho_t - 1
+            u = v[:2]
+            if clip: u = np.clip(u, -0.1, 0.1)
+            x = b['A_true'] @ x + b['B_true'] @ u
+        cnt[i] = c; area[i] = a
+    return cnt, area
+for clip in (False, True):
+    cnt, area = predicted(clip)
+    for name, key in ((f'pred count (clip={clip}) + rho0 tiebreak', cnt + 1e-3 * np.minimum(rho, 900)), (f'pred area (clip={clip})', area)):
+        f, per_wave = wave_frac(np.argsort(-key, kind='stable'))
+        print(f'{name:40s}: wave-steps needing IPM {f:.3f}; per-wave IPM steps: max {per_wave.max()} mean {per_wave.mean():.1f}')
