@@ -136,6 +136,7 @@ struct Spec {
     double v[RB];          // result of the last QP (shifted inputs), set at the end of solve_qp
     double x[NX];          // current state (replicated in the group)
     int r, s, lane;        // sub-lane in group, group in wave, lane in wave
+    unsigned prevL, prevU; // active sets (all rows of the group) of the previous QP of a rollout, 0 if it was interior
     double *lds;
 
     // half-width and centre of own row jb
@@ -558,7 +559,7 @@ struct Spec {
             }
             in = group_and<LPS>(in);
             inside = in != 0u;
-            if (!__any(!inside)) return 0;           // every instance of the wave is done, exactly
+            if (!__any(!inside)) { prevL = 0u; prevU = 0u; return 0; }   // every instance of the wave is done, exactly
             double y[RB];
             symv(q, y);                              // q = -P v_unc for the instances that must iterate
 #pragma unroll
@@ -581,6 +582,16 @@ struct Spec {
             for (int jb = 0; jb < RB; ++jb) v[jb] = 0.0;
         }
         if (p.warm_start) {
+            // consecutive MPC problems: the previous optimum shifted by one stage predicts the active set
+            // better than the clipped unconstrained minimiser (the last stage keeps its own state)
+            if ((prevL | prevU) != 0u) {
+                constexpr unsigned tail = ((1u << NU) - 1u) << (n - NU);
+                const unsigned gl = (prevL >> NU) | (prevL & tail), gu = (prevU >> NU) | (prevU & tail);
+                unsigned own = 0u;
+#pragma unroll
+                for (int jb = 0; jb < RB; ++jb) own |= 1u << (jb * LPS + r_or0());
+                myL = gl & own; myU = gu & own;
+            }
             if (pdas(p, myL, myU, todo, 8, gtol, iters)) todo = false;
         }
         if (__any(todo)) {
@@ -605,8 +616,11 @@ struct Spec {
                     if (up) pu |= bit;
                 }
                 if (pdas(p, pl, pu, todo && st != 2, 3, gtol, iters) && todo && st != 2) status = 0;
+                if (todo) { myL = pl; myU = pu; }
             }
         }
+        prevL = inside ? 0u : group_or<LPS>(myL);
+        prevU = inside ? 0u : group_or<LPS>(myU);
         return status;
     }
 
@@ -642,6 +656,7 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
     st.lds = lds;
     const int lane = threadIdx.x;
     st.s = lane / LPS; st.r = lane % LPS; st.lane = lane;
+    st.prevL = 0u; st.prevU = 0u;
     const int r = st.r, s = st.s;
     const long long Bsz = p.Bsz;
     const long long b_raw = (long long)blockIdx.x * SPW + s;
@@ -965,6 +980,7 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
             double x0[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) { x0[i] = sh[p.so.x0s + i * p.K + k]; st.x[i] = x0[i]; }
+            st.prevL = 0u; st.prevU = 0u;            // unrelated initial states: no carry-over of the active set
             const int stt = st.solve_qp(p, iters);
             status = stt > status ? stt : status;
             const double vn = value_fn(x0);

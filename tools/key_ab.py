@@ -7,7 +7,8 @@ nx, nu, N, Bsz, T = 4, 2, 10, b['Bsz'], 30
 dA = torch.from_numpy(b['A']).to(dev); dB = torch.from_numpy(b['B']).to(dev); dx0 = torch.from_numpy(b['x0']).to(dev)
 dJT = torch.empty(Bsz, dtype=torch.float64, device=dev); dit = torch.empty(Bsz, dtype=torch.int32, device=dev); dst = torch.empty(Bsz, dtype=torch.int32, device=dev)
 s = BatchSolver(0, stream=torch.cuda.current_stream(dev).cuda_stream)
-for name, kw in (('natural nowarm', dict(order=0, warm_start=0)), ('sorted nowarm', dict(order=1, warm_start=0)), ('natural warm', dict(order=0, warm_start=1)), ('sorted warm', dict(order=1, warm_start=1))):
+import os
+for name, kw in (('natural warm', dict(order=0, warm_start=1)), ('sorted warm key=' + os.environ.get('LQMPC_KEY_MODE', '0'), dict(order=1, warm_start=1))):
     s.set_options(**kw)
     for rep in range(3):
         torch.cuda.synchronize(); t = time.perf_counter()
