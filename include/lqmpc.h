@@ -82,10 +82,11 @@ typedef struct lqmpc_options {
     int32_t presolve;  /* unconstrained-minimiser shortcut: the minimiser v = G x + v_r (G = -P^-1 Fq, built once
                           per instance) is tested against the box before any iteration; a QP whose minimiser is
                           interior is finished there, exactly.  -1 auto (= on), 0 off, 1 on.  Specialised kernels only; the generic kernel ignores it.  (default -1) */
-    int32_t order;     /* processing order of a rollout batch.  1: a probe launch computes per instance how far the
-                          unconstrained minimiser at x0 leaves the box, the batch is radix-sorted by that key and the
-                          rollout walks it hardest-first, so the instances that share a wavefront leave the constrained
-                          regime together (results are written back to their original positions).  0: natural order.
+    int32_t order;     /* processing order of a rollout batch.  1: a probe launch computes a difficulty key per instance
+                          (largest stage gradient of the free response over the horizon, in units of what one input
+                          can counter), the batch is radix-sorted by it and the rollout walks it hardest-first, so the
+                          instances that share a wavefront leave the constrained regime together; results are written
+                          back to their original positions and do not depend on the order.  0: natural order.
                           -1 auto (1 for specialised rollouts with presolve, T >= 4 and Bsz >= 1024).  (default -1) */
     int32_t warm_start; /* primal-dual active-set warm start: before the interior-point loop, the QP is solved exactly on
                           the face guessed from the unconstrained minimiser (rows outside the box sit on their bound)

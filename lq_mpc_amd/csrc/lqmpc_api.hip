@@ -7,7 +7,6 @@
 
 #include <cmath>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -245,7 +244,7 @@ static int prepare(lqmpc_handle *h, const Call &c, KParams &p)
     p.T = c.T; p.K = c.K; p.mode = c.mode;
     p.true_per_instance = c.true_per_instance;
     p.has_ref = (c.x_ref || c.u_ref) ? 1 : 0;
-    p.max_iter = h->opt.max_iter; p.polish = h->opt.polish; p.key_mode = getenv("LQMPC_KEY_MODE") ? atoi(getenv("LQMPC_KEY_MODE")) : 0;
+    p.max_iter = h->opt.max_iter; p.polish = h->opt.polish;
     p.presolve = h->opt.presolve < 0 ? 1 : h->opt.presolve;
     p.warm_start = h->opt.warm_start < 0 ? p.presolve : h->opt.warm_start;
     p.eps = h->opt.eps; p.tau = h->opt.tau; p.z0_scale = h->opt.z0_scale;

@@ -19,7 +19,7 @@ struct KParams {
     int T, K, mode;
     int true_per_instance;
     int has_ref;
-    int max_iter, polish, presolve, warm_start, key_mode;
+    int max_iter, polish, presolve, warm_start;
     double eps, tau, z0_scale;
     long long Bsz;
     long long ws_stride;   // generic kernel: instances per workspace entry row

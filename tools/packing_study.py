@@ -46,3 +46,21 @@ for clip in (False, True):
     for name, key in ((f'pred count (clip={clip}) + rho0 tiebreak', cnt + 1e-3 * np.minimum(rho, 900)), (f'pred area (clip={clip})', area)):
         f, per_wave = wave_frac(np.argsort(-key, kind='stable'))
         print(f'{name:40s}: wave-steps needing IPM {f:.3f}; per-wave IPM steps: max {per_wave.max()} mean {per_wave.mean():.1f}')
+
+# ---- cheap keys that need no condensing: one-stage-lookahead gradient, and N-stage free-response energy ----
+k1 = np.zeros(Bsz); k2 = np.zeros(Bsz)
+Q, R = b['Q'], b['R']
+for i in range(Bsz):
+    A, Bm, x = b['A'][:, :, i], b['B'][:, :, i], b['x0'][:, i]
+    g = Bm.T @ Q @ A @ x
+    d = np.diag(Bm.T @ Q @ Bm + R)
+    k1[i] = np.max(np.abs(g) / (d * 0.1))
+    # free response over the horizon weighted by B: sum_r |B' Q A^{r+1} x|
+    xx = x.copy(); acc = 0.0
+    for r in range(N):
+        xx = A @ xx
+        acc = max(acc, np.max(np.abs(Bm.T @ Q @ xx) / (d * 0.1)))
+    k2[i] = acc
+for name, key in (('one-stage gradient', k1), ('max over horizon of stage gradient', k2)):
+    f, per_wave = wave_frac(np.argsort(-key, kind='stable'))
+    print(f'{name:40s}: wave-steps needing IPM {f:.3f}; per-wave IPM steps: max {per_wave.max()} mean {per_wave.mean():.1f}')
