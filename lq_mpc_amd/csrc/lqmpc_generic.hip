@@ -198,30 +198,15 @@ __device__ static void condense(const Ctx &c)
     }
 }
 
-// ---- one box QP at the state in WS(x): result v (shifted input sequence) in WS(v) ----
-// returns status (0 ok, 1 iteration cap, 2 non-finite) and adds the iteration count to *iters
-__device__ static int solve_qp(const Ctx &c, int *iters)
+// ---- interior-point iterations from the current iterate until the gap / residual reach eps_rel ----
+// (Mehrotra predictor-corrector; the iterate lives in WS(sl, su, zl, zu, rd); `it` counts iterations of the
+// whole QP against max_iter).  Returns 0 converged, 1 iteration cap, 2 non-finite.
+__device__ static int ipm_stage(const Ctx &c, double scale, double eps_rel, int &it)
 {
     const KParams &p = c.p; double *ws = c.ws; const long long b = c.b, stride = c.stride;
-    const int nx = c.nx, nu = c.nu, n = c.n; const GenOff &o = c.o;
-    const double *lb = p.sh + p.so.lb, *ub = p.sh + p.so.ub;
-    double scale = 0.0;
-    for (int i = 0; i < n; ++i) {
-        double s = WS(o.qr, i);
-        for (int a = 0; a < nx; ++a) s = __builtin_fma(WS(o.F, i * nx + a), WS(o.x, a), s);
-        WS(o.q, i) = s;
-        scale = fmax(scale, fabs(s));
-    }
-    if (!(scale < 1e300)) { for (int i = 0; i < n; ++i) WS(o.v, i) = 0.0; return 2; }
-    scale = fmax(scale, 1e-100);
-    const double z0 = p.z0_scale * scale;
-    for (int i = 0; i < n; ++i) {
-        const int k = i % nu; const double h = 0.5 * (ub[k] - lb[k]);
-        WS(o.v, i) = 0.0; WS(o.sl, i) = h; WS(o.su, i) = h;
-        WS(o.zl, i) = z0; WS(o.zu, i) = z0; WS(o.rd, i) = WS(o.q, i);
-    }
+    const int n = c.n; const GenOff &o = c.o;
     const double inv2n = 1.0 / (2.0 * n);
-    int status = 1, it = 0;
+    int status = 1;
     for (; it <= p.max_iter; ++it) {
         double mu = 0.0, rn = 0.0, hmin = 1e300;
         for (int i = 0; i < n; ++i) {
@@ -231,7 +216,7 @@ __device__ static int solve_qp(const Ctx &c, int *iters)
         }
         mu *= inv2n;
         if (!(mu < 1e300) || !(rn < 1e300)) { status = 2; break; }
-        if (mu <= p.eps * scale * 0.5 * hmin && rn <= p.eps * scale) { status = 0; break; }
+        if (mu <= eps_rel * scale * 0.5 * hmin && rn <= eps_rel * scale) { status = 0; break; }
         if (it == p.max_iter) break;
         // K = P + diag(zl/sl + zu/su), factor
         for (int i = 0; i < n; ++i) {
@@ -278,7 +263,9 @@ __device__ static int solve_qp(const Ctx &c, int *iters)
             mp = fmax(mp, fmax(-dv * isl, dv * isu));
             md = fmax(md, fmax(-dzl / zl, -dzu / zu));
         }
-        const double ap = mp > p.tau ? p.tau / mp : 1.0, ad = md > p.tau ? p.tau / md : 1.0;
+        // one step length for primal and dual (unequal lengths can make the QP's dual residual oscillate)
+        mp = fmax(mp, md);
+        const double ap = mp > p.tau ? p.tau / mp : 1.0, ad = ap;
         for (int i = 0; i < n; ++i) {
             const double dv = WS(o.dv, i), dzl = WS(o.isl, i), dzu = WS(o.isu, i);
             WS(o.v, i) += ap * dv; WS(o.sl, i) += ap * dv; WS(o.su, i) -= ap * dv;
@@ -286,16 +273,25 @@ __device__ static int solve_qp(const Ctx &c, int *iters)
             WS(o.rd, i) = (1.0 - ap) * WS(o.rd, i) + (ap - ad) * (dzl - dzu);
         }
     }
-    *iters += it;
-    if (status == 2) return 2;
-    if (p.polish) {
-        *iters += 1;     // the polish is one more factorisation
-        // exact solve on the identified active set; accepted only if it satisfies the KKT conditions
+    return status;
+}
+
+// ---- primal-dual active-set iterations from the face suggested by the interior-point iterate ----
+// One iteration solves the QP on the face (WS(act): -1 lower, +1 upper, 0 free) exactly and re-derives the
+// face from the KKT signs; a fixed point is the exact optimum and is committed to WS(v).
+__device__ static bool pdas(const Ctx &c, double scale, int maxit, int *iters)
+{
+    const KParams &p = c.p; double *ws = c.ws; const long long b = c.b, stride = c.stride;
+    const int nu = c.nu, n = c.n; const GenOff &o = c.o;
+    const double *lb = p.sh + p.so.lb, *ub = p.sh + p.so.ub;
+    const double gt = 1e-10 * scale;
+    for (int i = 0; i < n; ++i)
+        WS(o.act, i) = (WS(o.zl, i) > WS(o.sl, i)) ? -1.0 : ((WS(o.zu, i) > WS(o.su, i)) ? 1.0 : 0.0);
+    for (int k = 0; k < maxit; ++k) {
+        *iters += 1;
         for (int i = 0; i < n; ++i) {
-            const int k = i % nu; const double h = 0.5 * (ub[k] - lb[k]);
-            const double a = (WS(o.zl, i) > WS(o.sl, i)) ? -1.0 : ((WS(o.zu, i) > WS(o.su, i)) ? 1.0 : 0.0);
-            WS(o.act, i) = a;
-            WS(o.dva, i) = a * h;   // bound value (0 for free)
+            const int kk = i % nu; const double h = 0.5 * (ub[kk] - lb[kk]);
+            WS(o.dva, i) = WS(o.act, i) * h;   // bound value (0 for free)
         }
         for (int i = 0; i < n; ++i) {
             const bool ai = WS(o.act, i) != 0.0;
@@ -307,20 +303,70 @@ __device__ static int solve_qp(const Ctx &c, int *iters)
             }
             WS(o.dv, i) = r;
         }
-        bool ok = chol_packed(c);
+        if (!chol_packed(c)) return false;
         chol_solve_packed(c, o.dv);
-        const double gt = 1e-9 * scale;
-        for (int i = 0; i < n && ok; ++i) {
-            const int k = i % nu; const double h = 0.5 * (ub[k] - lb[k]);
-            const double a = WS(o.act, i);
-            if (a == 0.0) { if (!(fabs(WS(o.dv, i)) <= h * (1.0 + 1e-12))) ok = false; }
+        bool changed = false;
+        for (int i = 0; i < n; ++i) {
+            const int kk = i % nu; const double h = 0.5 * (ub[kk] - lb[kk]);
+            const double a = WS(o.act, i), vi = WS(o.dv, i);
+            if (!(fabs(vi) < 1e300)) return false;
+            double na;
+            if (a == 0.0) na = (vi < -h * (1.0 + 1e-12)) ? -1.0 : ((vi > h * (1.0 + 1e-12)) ? 1.0 : 0.0);
             else {
-                double g = WS(o.q, i);
-                for (int j = 0; j < n; ++j) g = __builtin_fma(psym(c, i, j), WS(o.dv, j), g);
-                if (a < 0.0 ? !(g >= -gt) : !(g <= gt)) ok = false;
+                double gi = WS(o.q, i);
+                for (int j = 0; j < n; ++j) gi = __builtin_fma(psym(c, i, j), WS(o.dv, j), gi);
+                na = (a < 0.0) ? ((gi >= -gt) ? -1.0 : 0.0) : ((gi <= gt) ? 1.0 : 0.0);
             }
+            WS(o.isl, i) = na;              // new face, applied after the sweep
+            changed = changed || (na != a);
         }
-        if (ok) for (int i = 0; i < n; ++i) WS(o.v, i) = WS(o.dv, i);
+        if (!changed) {
+            for (int i = 0; i < n; ++i) WS(o.v, i) = WS(o.dv, i);
+            return true;
+        }
+        for (int i = 0; i < n; ++i) WS(o.act, i) = WS(o.isl, i);
+    }
+    return false;
+}
+
+// ---- one box QP at the state in WS(x): result v (shifted input sequence) in WS(v) ----
+// Interior point in stages (gap 1e-6, 1e-9, eps); after each stage the active-set iterations try to finish
+// exactly from the face the iterate suggests.  Returns status (0 ok, 1 iteration cap, 2 non-finite) and adds
+// the number of KKT factorisations to *iters.
+__device__ static int solve_qp(const Ctx &c, int *iters)
+{
+    const KParams &p = c.p; double *ws = c.ws; const long long b = c.b, stride = c.stride;
+    const int nx = c.nx, nu = c.nu, n = c.n; const GenOff &o = c.o;
+    const double *lb = p.sh + p.so.lb, *ub = p.sh + p.so.ub;
+    double scale = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double s = WS(o.qr, i);
+        for (int a = 0; a < nx; ++a) s = __builtin_fma(WS(o.F, i * nx + a), WS(o.x, a), s);
+        WS(o.q, i) = s;
+        scale = fmax(scale, fabs(s));
+    }
+    if (!(scale < 1e300)) { for (int i = 0; i < n; ++i) WS(o.v, i) = 0.0; return 2; }
+    scale = fmax(scale, 1e-100);
+    const double z0 = p.z0_scale * scale;
+    for (int i = 0; i < n; ++i) {
+        const int k = i % nu; const double h = 0.5 * (ub[k] - lb[k]);
+        WS(o.v, i) = 0.0; WS(o.sl, i) = h; WS(o.su, i) = h;
+        WS(o.zl, i) = z0; WS(o.zu, i) = z0; WS(o.rd, i) = WS(o.q, i);
+    }
+    int status = 1, it = 0;
+    double e_prev = 1e300;
+    for (int stage = 0; stage < 3; ++stage) {
+        const double e = !p.polish ? p.eps : (stage == 0 ? fmax(1e-6, p.eps) : (stage == 1 ? fmax(1e-9, p.eps) : p.eps));
+        if (!(e < e_prev)) continue;
+        e_prev = e;
+        const int it0 = it;
+        status = ipm_stage(c, scale, e, it);
+        *iters += it - it0;
+        if (status == 2) { for (int i = 0; i < n; ++i) WS(o.v, i) = 0.0; return 2; }
+        // WS(v) holds the interior-point iterate (tracked alongside the slacks)
+        if (!p.polish) break;
+        if (pdas(c, scale, 6, iters)) { status = 0; break; }
+        if (it >= p.max_iter) break;
     }
     return status;
 }

@@ -423,25 +423,30 @@ struct Spec {
     }
 
     // ---- Mehrotra predictor-corrector interior point on min 1/2 v'Pv + qs'v, |v| <= h ----
-    // Groups with run == false are frozen (their state is initialised but never stepped).  Leaves the
-    // iterate in sl, su, zl, zu; returns 0 converged, 1 iteration cap, 2 non-finite.
-    __device__ __forceinline__ int ipm(const KParams &p, bool run, double scale, int &iters)
+    // ipm_init places the iterate at the box centre; ipm_run advances it until the complementarity gap and
+    // the dual residual are below eps_rel (relative to |q|_inf) or the wave's iteration budget is spent, and
+    // can be called again with a tighter eps_rel.  Groups with run == false are frozen.  The iterate lives
+    // in sl, su, zl, zu; returns 0 converged, 1 budget exhausted, 2 non-finite.
+    __device__ __forceinline__ void ipm_init(const KParams &p, double scale)
     {
         const double z0 = p.z0_scale * scale;
-        double hmin = 1e300;
 #pragma unroll
         for (int jb = 0; jb < RB; ++jb) {
             const double h = hh(p, jb);
-            hmin = fmin(hmin, h);
             sl[jb] = h; su[jb] = h; zl[jb] = z0; zu[jb] = z0; rd[jb] = qs.get(jb);
         }
+    }
+    __device__ __forceinline__ int ipm_run(const KParams &p, bool run, double scale, double eps_rel, int &budget, int &iters)
+    {
+        double hmin = 1e300;
+#pragma unroll
+        for (int jb = 0; jb < RB; ++jb) hmin = fmin(hmin, hh(p, jb));
         hmin = group_max<LPS>(-hmin); hmin = -hmin;
         const double inv2n = 1.0 / (2.0 * n);
-        const double mu_tol = p.eps * scale * hmin, rd_tol = p.eps * scale;
+        const double mu_tol = eps_rel * scale * hmin, rd_tol = eps_rel * scale;
         int status = 1;
         bool live = run;                  // this group still iterates
-        int it = 0;
-        for (; it < p.max_iter; ++it) {
+        for (; budget > 0; --budget) {
             double mu = 0.0, rn = 0.0;
 #pragma unroll
             for (int jb = 0; jb < RB; ++jb) {
@@ -521,8 +526,12 @@ struct Spec {
                 md = fmax(md, fmax(-dzl[jb] * frcp(zl[jb]), -dzu[jb] * frcp(zu[jb])));
             }
             mp = group_max<LPS>(mp); md = group_max<LPS>(md);
-            double ap = mp > p.tau ? p.tau * frcp(mp) : 1.0, ad = md > p.tau ? p.tau * frcp(md) : 1.0;
-            if (!live) { ap = 0.0; ad = 0.0; }
+            // one step length for primal and dual: with unequal lengths the dual residual of a QP is not
+            // monotone and the iteration can cycle (observed on weakly active constraints)
+            mp = fmax(mp, md);
+            double ap = mp > p.tau ? p.tau * frcp(mp) : 1.0;
+            if (!live) ap = 0.0;
+            const double ad = ap;
 #pragma unroll
             for (int jb = 0; jb < RB; ++jb) {
                 const double st = ap * dv[jb];
@@ -595,28 +604,40 @@ struct Spec {
             if (pdas(p, myL, myU, todo, 8, gtol, iters)) todo = false;
         }
         if (__any(todo)) {
-            const int st = ipm(p, todo, scale, iters);
-            if (todo) {
-                status = st;
-                if (st == 2) {
+            // Fallback.  With the polish on, the interior-point loop is run in stages (gap 1e-6, 1e-9, eps) and
+            // after each stage the active-set iterations try to finish from the face it suggests (z > s): a
+            // verified fixed point ends the solve early, and slow interior-point tails (weakly active
+            // constraints) never have to reach eps on their own.
+            ipm_init(p, scale);
+            int budget = p.max_iter;
+            double e_prev = 1e300;
+#pragma unroll 1
+            for (int stage = 0; stage < 3; ++stage) {
+                const double e = !p.polish ? p.eps : (stage == 0 ? fmax(1e-6, p.eps) : (stage == 1 ? fmax(1e-9, p.eps) : p.eps));
+                if (!(e < e_prev)) continue;        // nothing tighter left to do
+                e_prev = e;
+                const int st = ipm_run(p, todo, scale, e, budget, iters);
+                if (todo) {
+                    status = st;
 #pragma unroll
-                    for (int jb = 0; jb < RB; ++jb) v[jb] = 0.0;
+                    for (int jb = 0; jb < RB; ++jb) v[jb] = (st == 2) ? 0.0 : sl[jb] - hh(p, jb);   // interior-point answer
+                }
+                if (p.polish) {
+                    unsigned pl = 0u, pu = 0u;
+#pragma unroll
+                    for (int jb = 0; jb < RB; ++jb) {
+                        const unsigned bit = 1u << (jb * LPS + r_or0());
+                        const bool lo = zl[jb] > sl[jb], up = (!lo) && (zu[jb] > su[jb]);
+                        if (lo) pl |= bit;
+                        if (up) pu |= bit;
+                    }
+                    const bool fixed = pdas(p, pl, pu, todo && st != 2, 4, gtol, iters);
+                    if (todo && st != 2 && fixed) { status = 0; myL = pl; myU = pu; todo = false; }
+                    if (todo && st == 2) todo = false;
                 } else {
-#pragma unroll
-                    for (int jb = 0; jb < RB; ++jb) v[jb] = sl[jb] - hh(p, jb);      // interior-point answer
+                    todo = false;
                 }
-            }
-            if (p.polish) {
-                unsigned pl = 0u, pu = 0u;
-#pragma unroll
-                for (int jb = 0; jb < RB; ++jb) {
-                    const unsigned bit = 1u << (jb * LPS + r_or0());
-                    const bool lo = zl[jb] > sl[jb], up = (!lo) && (zu[jb] > su[jb]);
-                    if (lo) pl |= bit;
-                    if (up) pu |= bit;
-                }
-                if (pdas(p, pl, pu, todo && st != 2, 3, gtol, iters) && todo && st != 2) status = 0;
-                if (todo) { myL = pl; myU = pu; }
+                if (!__any(todo) || budget <= 0) break;
             }
         }
         prevL = inside ? 0u : group_or<LPS>(myL);

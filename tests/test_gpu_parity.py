@@ -280,3 +280,42 @@ def test_difficulty_ordering_is_transparent(solver, golden_dir):
     sub = dict(b, A=np.ascontiguousarray(b["A"][:, :, idx]), B=np.ascontiguousarray(b["B"][:, :, idx]))
     ref = orc.rollout_batch(20, *args(sub), np.ascontiguousarray(b["x0"][:, idx]), b["A_true"], b["B_true"])
     assert rel(r1["J_T"][idx], ref["J_T"]) < TIGHT
+
+
+# ---------------- stress: random shapes of cost, box, conditioning on the specialised shapes ----------------
+@pytest.mark.parametrize("nx,nu,N", [(4, 2, 10), (2, 1, 10), (2, 1, 5), (3, 2, 6), (1, 1, 1), (5, 3, 4), (4, 2, 20)])
+@pytest.mark.parametrize("warm", [0, 1])
+def test_random_problems(solver, nx, nu, N, warm):
+    """Unstable / badly scaled models, dense Q/R/P, asymmetric boxes, references, per-instance plants, on the
+    specialised shapes (warm start on / off) and on shapes only the generic kernel covers."""
+    rng = np.random.default_rng(100 * nx + N + warm)
+    Bsz, T = 768, 12
+    A = rng.standard_normal((nx, nx, Bsz))
+    A *= rng.uniform(0.3, 1.3, Bsz) / np.abs(np.linalg.eigvals(A.transpose(2, 0, 1))).max(axis=1)      # spectral radius in [0.3, 1.3]
+    B = rng.standard_normal((nx, nu, Bsz)) * rng.uniform(0.1, 2.0, (1, 1, Bsz))
+    def spd(m, lo, hi):
+        M = rng.standard_normal((m, m)); M = M @ M.T / m + np.eye(m)
+        return M * rng.uniform(lo, hi)
+    Q, R, P = spd(nx, 0.5, 5.0), spd(nu, 0.05, 2.0), spd(nx, 0.5, 20.0)
+    lb, ub = -rng.uniform(0.05, 0.5, nu), rng.uniform(0.05, 0.5, nu)
+    x0 = rng.standard_normal((nx, Bsz)) * rng.choice([1e-3, 0.1, 1.0, 10.0], Bsz)
+    xr, ur = 0.2 * rng.standard_normal((nx, N)), 0.05 * rng.standard_normal((nu, N))
+    At = np.ascontiguousarray(A * 0.9 + 0.02 * rng.standard_normal((nx, nx, Bsz)))
+    Bt = np.ascontiguousarray(B + 0.02 * rng.standard_normal((nx, nu, Bsz)))
+    A, B = np.ascontiguousarray(A), np.ascontiguousarray(B)
+    umax = float(np.max(np.maximum(-lb, ub)))
+    try:
+        solver.set_options(warm_start=warm, presolve=warm)
+        g1 = solver.solve_batch(N, A, B, Q, R, P, lb, ub, x0, xr, ur)
+        g2 = solver.rollout_batch(T, N, A, B, Q, R, P, lb, ub, x0, At, Bt, xr, ur, want_traj=True)
+        assert ("spec" in solver.last_kernel()) == ((nx, nu, N) in [(4, 2, 10), (2, 1, 10), (2, 1, 5)])
+    finally:
+        solver.set_options(warm_start=-1, presolve=-1)
+    r1 = orc.solve_batch(N, A, B, Q, R, P, lb, ub, x0, xr, ur)
+    r2 = orc.rollout_batch(T, N, A, B, Q, R, P, lb, ub, x0, At, Bt, xr, ur, want_traj=True)
+    assert np.all(g1["status"] == 0)
+    assert rel(g1["V_N"], r1["V_N"]) < 1e-7 and u_err(g1["u_0"], r1["u_0"], umax) < RTOL
+    ok = np.isfinite(r2["J_T"]) & (np.abs(r2["X"]).max(axis=(0, 1)) < 1e6)     # diverging plants amplify round-off
+    assert ok.mean() > 0.5 and np.all(g2["status"][ok] == 0)
+    assert rel(g2["J_T"][ok], r2["J_T"][ok]) < 1e-6
+    assert u_err(g2["U"][:, :3, ok], r2["U"][:, :3, ok], umax) < RTOL
