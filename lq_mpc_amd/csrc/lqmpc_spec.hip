@@ -17,6 +17,8 @@
 // interior-point method replaces cvxpy's QP back-end (utils_class.py:84-88).
 #include "lqmpc_common.h"
 
+#include <type_traits>
+
 namespace lqmpc {
 
 // ---------------- cross-lane primitives inside a group of LPS lanes ----------------
@@ -40,15 +42,46 @@ __device__ __forceinline__ unsigned dpp_mov_u32(unsigned x)
 template <int LPS, int SRC>
 __device__ __forceinline__ double bcast(double x)
 {
-    static_assert(LPS == 1 || LPS == 2 || LPS == 4, "quad_perm covers groups of 1, 2, 4 lanes");
+    static_assert(LPS == 1 || LPS == 2 || LPS == 4 || LPS == 64, "groups of 1, 2, 4 lanes (quad_perm) or the whole wave");
     if constexpr (LPS == 1) return x;
     else if constexpr (LPS == 2) return dpp_mov<(SRC == 0) ? 0xA0 : 0xF5>(x);   // [0,0,2,2] / [1,1,3,3]
-    else return dpp_mov<SRC * 0x55>(x);                                          // [s,s,s,s]
+    else if constexpr (LPS == 4) return dpp_mov<SRC * 0x55>(x);                  // [s,s,s,s]
+    else {
+        // whole wave: v_readlane_b32 puts lane SRC's value in SGPRs, i.e. the broadcast is a scalar operand
+        const int lo = __builtin_amdgcn_readlane(__double2loint(x), SRC), hi = __builtin_amdgcn_readlane(__double2hiint(x), SRC);
+        return __hiloint2double(hi, lo);
+    }
+}
+
+// wave-wide reductions (LPS == 64): quad_perm x2, row_half_mirror, row_mirror leave every lane with its
+// 16-lane row's result; row_bcast15 / row_bcast31 carry it across rows into lane 63, which is broadcast.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_rows(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);   // lanes outside ROWMASK keep x
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <bool MAX>
+__device__ __forceinline__ double wave_reduce(double x)
+{
+#define LQ_OP(a, b) (MAX ? fmax((a), (b)) : (a) + (b))
+    x = LQ_OP(x, dpp_mov<0xB1>(x));
+    x = LQ_OP(x, dpp_mov<0x4E>(x));
+    x = LQ_OP(x, (dpp_rows<0x141, 0xF>(x)));                      // row_half_mirror
+    x = LQ_OP(x, (dpp_rows<0x140, 0xF>(x)));                      // row_mirror
+    const int row = threadIdx.x >> 4;
+    { const double y = dpp_rows<0x142, 0xA>(x); if (row & 1) x = LQ_OP(x, y); }   // row_bcast15 into rows 1, 3
+    { const double y = dpp_rows<0x143, 0xC>(x); if (row & 2) x = LQ_OP(x, y); }   // row_bcast31 into rows 2, 3
+#undef LQ_OP
+    return bcast<64, 63>(x);
 }
 
 template <int LPS>
 __device__ __forceinline__ double group_sum(double x)
 {
+    if constexpr (LPS == 64) return wave_reduce<false>(x);
     if constexpr (LPS >= 2) x += dpp_mov<0xB1>(x);   // [1,0,3,2]
     if constexpr (LPS >= 4) x += dpp_mov<0x4E>(x);   // [2,3,0,1]
     return x;
@@ -56,20 +89,28 @@ __device__ __forceinline__ double group_sum(double x)
 template <int LPS>
 __device__ __forceinline__ double group_max(double x)
 {
+    if constexpr (LPS == 64) return wave_reduce<true>(x);
     if constexpr (LPS >= 2) x = fmax(x, dpp_mov<0xB1>(x));
     if constexpr (LPS >= 4) x = fmax(x, dpp_mov<0x4E>(x));
     return x;
 }
-template <int LPS>
-__device__ __forceinline__ unsigned group_or(unsigned x)
+template <int LPS, typename M>
+__device__ __forceinline__ M group_or(M x)
 {
-    if constexpr (LPS >= 2) x |= dpp_mov_u32<0xB1>(x);
-    if constexpr (LPS >= 4) x |= dpp_mov_u32<0x4E>(x);
-    return x;
+    if constexpr (LPS == 64) {
+        // one row per lane: a lane's mask can only hold its own bit, so the union is a ballot
+        return (M)__ballot(x != 0);
+    } else {
+        unsigned y = (unsigned)x;
+        if constexpr (LPS >= 2) y |= dpp_mov_u32<0xB1>(y);
+        if constexpr (LPS >= 4) y |= dpp_mov_u32<0x4E>(y);
+        return (M)y;
+    }
 }
 template <int LPS>
-__device__ __forceinline__ unsigned group_and(unsigned x)
+__device__ __forceinline__ unsigned group_and(unsigned x)     // x in {0, 1}
 {
+    if constexpr (LPS == 64) return __all(x != 0) ? 1u : 0u;
     if constexpr (LPS >= 2) x &= dpp_mov_u32<0xB1>(x);
     if constexpr (LPS >= 4) x &= dpp_mov_u32<0x4E>(x);
     return x;
@@ -101,14 +142,14 @@ struct AccArr {
 template <int NX, int NU, int N, int LPS>
 struct Spec {
     static constexpr int n = N * NU;
-    static_assert(n % LPS == 0, "n must be a multiple of the group width");
+    static_assert(LPS == 64 ? (n > 4 && n <= 64) : (n % LPS == 0 && n <= 32), "n must be a multiple of the group width (<= 32), or <= 64 for a whole wave");
     static_assert(LPS == 1 || LPS % NU == 0, "group width must be a multiple of nu");
-    static_assert(n <= 32, "active-set bit mask is 32 bits wide");
-    static constexpr int RB = n / LPS;              // rows per lane
+    typedef typename std::conditional<(n > 32), unsigned long long, unsigned>::type mask_t;   // one bit per row
+    static constexpr int RB = (n + LPS - 1) / LPS;  // rows per lane (LPS == 64: one, lanes >= n are padding)
     static constexpr int SPW = 64 / LPS;            // instances per wave
-    static constexpr int TRI = LPS * RB * (RB + 1) / 2;
-    __host__ __device__ static constexpr int off(int jb) { return LPS * jb * (jb + 1) / 2; }
-    __host__ __device__ static constexpr int rowlen(int jb) { return (jb + 1) * LPS; }
+    __host__ __device__ static constexpr int rowlen(int jb) { return (jb + 1) * LPS < n ? (jb + 1) * LPS : n; }
+    __host__ __device__ static constexpr int off(int jb) { return LPS == 64 ? jb * n : LPS * jb * (jb + 1) / 2; }   // closed form: stays a constant after unrolling
+    static constexpr int TRI = off(RB);
     // LDS mirror of L, column-major: column c holds row-blocks jb >= c/LPS, 64 doubles each.
     // Inside a 64-double block the element of instance s, row-sub-lane rr sits at
     // s*LPS + (rr ^ (c % LPS)): the Cholesky's column writes (all lanes in one column) and the
@@ -136,8 +177,16 @@ struct Spec {
     double v[RB];          // result of the last QP (shifted inputs), set at the end of solve_qp
     double x[NX];          // current state (replicated in the group)
     int r, s, lane;        // sub-lane in group, group in wave, lane in wave
-    unsigned prevL, prevU; // active sets (all rows of the group) of the previous QP of a rollout, 0 if it was interior
+    bool pad;              // LPS == 64: this lane holds no row (r >= n); it must not influence any reduction
+    mask_t prevL, prevU;   // active sets (all rows of the group) of the previous QP of a rollout, 0 if it was interior
     double *lds;
+
+    // group-wide reductions; with one row per lane (LPS == 64) the lanes without a row are neutral
+    __device__ __forceinline__ double gsum(double x) const { return group_sum<LPS>((LPS == 64 && pad) ? 0.0 : x); }
+    __device__ __forceinline__ double gmax(double x) const { return group_max<LPS>((LPS == 64 && pad) ? -1e308 : x); }
+    __device__ __forceinline__ mask_t gor(mask_t x) const { return group_or<LPS, mask_t>((LPS == 64 && pad) ? mask_t(0) : x); }
+    __device__ __forceinline__ unsigned gand(unsigned x) const { return group_and<LPS>((LPS == 64 && pad) ? 1u : x); }
+    __device__ __forceinline__ mask_t rowbit(int jb) const { return mask_t(1) << (jb * LPS + r_or0()); }
 
     // half-width and centre of own row jb
     __device__ __forceinline__ double hh(const KParams &p, int jb) const
@@ -200,6 +249,10 @@ struct Spec {
 #pragma unroll
                     for (int jb = c; jb < RB; ++jb) a[off(jb) + c] = __builtin_fma(-a[off(jb) + k], lck, a[off(jb) + c]);
                 }
+            } else if constexpr (LPS == 64) {
+                // one row per lane: l_ck comes out of lane c as a scalar operand (rows above c update padding only)
+#pragma unroll
+                for (int c = k + 2; c < n; ++c) a[c] = __builtin_fma(-a[k], bcast_rt(a[k], c), a[c]);
             } else {
 #pragma unroll
                 for (int c0 = (k + 2) & ~1; c0 < n; c0 += 2) {
@@ -228,7 +281,10 @@ struct Spec {
     {
         if constexpr (LPS == 1) return xv;
         else if constexpr (LPS == 2) return src == 0 ? bcast<2, 0>(xv) : bcast<2, 1>(xv);
-        else {
+        else if constexpr (LPS == 64) {
+            const int lo = __builtin_amdgcn_readlane(__double2loint(xv), src), hi = __builtin_amdgcn_readlane(__double2hiint(xv), src);
+            return __hiloint2double(hi, lo);
+        } else {
             switch (src) {
             case 0: return bcast<4, 0>(xv);
             case 1: return bcast<4, 1>(xv);
@@ -263,6 +319,14 @@ struct Spec {
                 const double xk = b[k] * invd[k];
 #pragma unroll
                 for (int jb = 0; jb < k; ++jb) b[jb] = __builtin_fma(-a[off(k) + jb], xk, b[jb]);   // l_{k,jb} from my own row k
+            }
+        } else if constexpr (LPS == 64) {
+            // one row per lane: l_{k,r} sits in mirror column r (clamped for the lanes without a row), slot k ^ r
+            const int col = (r < n ? r : n - 1) * 64;
+#pragma unroll
+            for (int k = n - 1; k >= 0; --k) {
+                const double xk = bcast_rt(b[0] * invd[0], k);
+                b[0] = __builtin_fma(-lds[col + (k ^ r)], xk, b[0]);
             }
         } else {
             // l_{k,i} for my column i = jb*LPS + r sits in mirror column i, row k (zero when i >= k).  The
@@ -318,6 +382,13 @@ struct Spec {
     // ---- y = P w for a row-distributed w (symmetric product from the stored lower part) ----
     __device__ __forceinline__ void symv(const double (&w)[RB], double (&y)[RB]) const
     {
+        if constexpr (LPS == 64) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < n; ++j) acc = __builtin_fma(Pm.get(j), bcast_rt(w[0], j), acc);
+            y[0] = acc;
+            return;
+        }
 #pragma unroll
         for (int jb = 0; jb < RB; ++jb) y[jb] = 0.0;
 #pragma unroll
@@ -333,7 +404,7 @@ struct Spec {
                 y[jb] = __builtin_fma(low ? pij : 0.0, wj, y[jb]);
                 tj = __builtin_fma(strict ? pij : 0.0, w[jb], tj);
             }
-            tj = group_sum<LPS>(tj);
+            tj = gsum(tj);
             if (LPS == 1 || r == j % LPS) y[j / LPS] += tj;
             if constexpr (LPS > 1) { if (j % LPS == LPS - 1) __builtin_amdgcn_sched_barrier(0); }
         }
@@ -346,16 +417,16 @@ struct Spec {
     // sign is released.  A fixed point satisfies every KKT condition, i.e. it is the exact optimum; it is
     // committed to v[] only then.  Serves as warm start (sets guessed from the unconstrained minimiser)
     // and as polish (sets read off the interior-point iterate).  Groups with run == false are untouched.
-    __device__ __forceinline__ bool pdas(const KParams &p, unsigned &myL, unsigned &myU, bool run, int maxit, double gtol, int &nfact)
+    __device__ __forceinline__ bool pdas(const KParams &p, mask_t &myL, mask_t &myU, bool run, int maxit, double gtol, int &nfact)
     {
         bool conv = !run, dead = false;
         for (int k = 0; k < maxit; ++k) {
             if (!__any(!conv && !dead)) break;
-            const unsigned colmask = group_or<LPS>(myL | myU);
+            const mask_t colmask = gor(myL | myU);
             double rhs[RB];
 #pragma unroll
             for (int jb = 0; jb < RB; ++jb) {
-                const unsigned bit = 1u << (jb * LPS + r_or0());
+                const mask_t bit = rowbit(jb);
                 const double h = hh(p, jb);
                 rhs[jb] = (myL & bit) ? -h : ((myU & bit) ? h : 0.0);
             }
@@ -365,18 +436,18 @@ struct Spec {
                 symv(rhs, pd);
 #pragma unroll
                 for (int jb = 0; jb < RB; ++jb)
-                    if (!((myL | myU) & (1u << (jb * LPS + r_or0())))) rhs[jb] = -(qs.get(jb) + pd[jb]);
+                    if (!((myL | myU) & rowbit(jb))) rhs[jb] = -(qs.get(jb) + pd[jb]);
             } else {
 #pragma unroll
                 for (int jb = 0; jb < RB; ++jb) rhs[jb] = -qs.get(jb);
             }
 #pragma unroll
             for (int jb = 0; jb < RB; ++jb) {
-                const bool ai = (myL | myU) & (1u << (jb * LPS + r_or0()));
+                const bool ai = ((myL | myU) & rowbit(jb)) != 0;
 #pragma unroll
                 for (int j = 0; j < rowlen(jb); ++j) {
                     const bool diag = (LPS == 1) ? (j == jb) : (j - jb * LPS == r);
-                    const bool aj = (colmask >> j) & 1u;
+                    const bool aj = ((colmask >> j) & 1u) != 0;
                     const double pv = Pm.get(off(jb) + j);     // read unconditionally: no branch per element
                     a[off(jb) + j] = (ai || aj) ? (diag ? 1.0 : 0.0) : pv;
                 }
@@ -392,20 +463,21 @@ struct Spec {
 #pragma unroll
                 for (int jb = 0; jb < RB; ++jb) g[jb] = -qs.get(jb);
             }
-            unsigned nl = 0u, nu = 0u, fin = ok ? 1u : 0u;
+            mask_t nl = 0, nu = 0;
+            unsigned fin = ok ? 1u : 0u;
 #pragma unroll
             for (int jb = 0; jb < RB; ++jb) {
-                const unsigned bit = 1u << (jb * LPS + r_or0());
+                const mask_t bit = rowbit(jb);
                 const double h = hh(p, jb), vi = rhs[jb], gi = g[jb] + qs.get(jb);
-                const bool isL = myL & bit, isU = myU & bit;
+                const bool isL = (myL & bit) != 0, isU = (myU & bit) != 0;
                 const bool toL = isL ? (gi >= -gtol) : (!isU && vi < -h * (1.0 + 1e-12));
                 const bool toU = isU ? (gi <= gtol) : (!isL && vi > h * (1.0 + 1e-12));
                 if (toL) nl |= bit;
                 if (toU) nu |= bit;
                 if (!(fabs(vi) < 1e300)) fin = 0u;
             }
-            const bool changed = group_or<LPS>((nl ^ myL) | (nu ^ myU)) != 0u;
-            fin = group_and<LPS>(fin);
+            const bool changed = gor((nl ^ myL) | (nu ^ myU)) != 0;
+            fin = gand(fin);
             if (!conv && !dead) {
                 nfact += 1;
                 if (!fin) dead = true;
@@ -441,7 +513,7 @@ struct Spec {
         double hmin = 1e300;
 #pragma unroll
         for (int jb = 0; jb < RB; ++jb) hmin = fmin(hmin, hh(p, jb));
-        hmin = group_max<LPS>(-hmin); hmin = -hmin;
+        hmin = gmax(-hmin); hmin = -hmin;
         const double inv2n = 1.0 / (2.0 * n);
         const double mu_tol = eps_rel * scale * hmin, rd_tol = eps_rel * scale;
         int status = 1;
@@ -453,8 +525,8 @@ struct Spec {
                 mu = __builtin_fma(sl[jb], zl[jb], mu); mu = __builtin_fma(su[jb], zu[jb], mu);
                 rn = fmax(rn, fabs(rd[jb]));
             }
-            mu = group_sum<LPS>(mu) * inv2n;
-            rn = group_max<LPS>(rn);
+            mu = gsum(mu) * inv2n;
+            rn = gmax(rn);
             if (live) {
                 if (!(mu < 1e300) || !(rn < 1e300)) { status = 2; live = false; }
                 else if (mu <= mu_tol && rn <= rd_tol) { status = 0; live = false; }
@@ -489,7 +561,7 @@ struct Spec {
                 mp = fmax(mp, fmax(-e, f));
                 md = fmax(md, fmax(1.0 + e, 1.0 - f));      // -dz_aff / z
             }
-            mp = group_max<LPS>(mp); md = group_max<LPS>(md);
+            mp = gmax(mp); md = gmax(md);
             const double apa = mp > 1.0 ? frcp(mp) : 1.0, ada = md > 1.0 ? frcp(md) : 1.0;
             double mua = 0.0;
 #pragma unroll
@@ -499,7 +571,7 @@ struct Spec {
                 mua = __builtin_fma(__builtin_fma(apa, d, sl[jb]), __builtin_fma(ada, dzl, zl[jb]), mua);
                 mua = __builtin_fma(__builtin_fma(-apa, d, su[jb]), __builtin_fma(ada, dzu, zu[jb]), mua);
             }
-            mua = group_sum<LPS>(mua) * inv2n;
+            mua = gsum(mua) * inv2n;
             double sg = mua * frcp(mu);
             sg = sg * sg * sg;
             const double smu = sg * mu;
@@ -525,7 +597,7 @@ struct Spec {
                 mp = fmax(mp, fmax(-dv[jb] * isl[jb], dv[jb] * isu[jb]));
                 md = fmax(md, fmax(-dzl[jb] * frcp(zl[jb]), -dzu[jb] * frcp(zu[jb])));
             }
-            mp = group_max<LPS>(mp); md = group_max<LPS>(md);
+            mp = gmax(mp); md = gmax(md);
             // one step length for primal and dual: with unequal lengths the dual residual of a QP is not
             // monotone and the iteration can cycle (observed on weakly active constraints)
             mp = fmax(mp, md);
@@ -553,22 +625,22 @@ struct Spec {
         double q[RB];
         linear_term(q);
         bool inside = false;
-        unsigned myL = 0u, myU = 0u;
+        mask_t myL = 0, myU = 0;
         if (p.presolve) {
             // LDS holds G = -P^-1 Fq and qr holds v_r: q is the unconstrained minimiser v_unc = G x + v_r.
             unsigned in = 1u;
 #pragma unroll
             for (int jb = 0; jb < RB; ++jb) {
-                const unsigned bit = 1u << (jb * LPS + r_or0());
+                const mask_t bit = rowbit(jb);
                 const double h = hh(p, jb);
                 v[jb] = q[jb];
                 if (!(fabs(q[jb]) <= h)) in = 0u;
                 if (q[jb] < -h) myL |= bit;
                 if (q[jb] > h) myU |= bit;
             }
-            in = group_and<LPS>(in);
+            in = gand(in);
             inside = in != 0u;
-            if (!__any(!inside)) { prevL = 0u; prevU = 0u; return 0; }   // every instance of the wave is done, exactly
+            if (!__any(!inside)) { prevL = 0; prevU = 0; return 0; }   // every instance of the wave is done, exactly
             double y[RB];
             symv(q, y);                              // q = -P v_unc for the instances that must iterate
 #pragma unroll
@@ -580,7 +652,7 @@ struct Spec {
         double scale = 0.0;
 #pragma unroll
         for (int jb = 0; jb < RB; ++jb) scale = fmax(scale, fabs(q[jb]));
-        scale = group_max<LPS>(scale);
+        scale = gmax(scale);
         const bool finite_in = scale < 1e300;
         scale = fmax(scale, 1e-100);
         const double gtol = 1e-10 * scale;
@@ -593,12 +665,12 @@ struct Spec {
         if (p.warm_start) {
             // consecutive MPC problems: the previous optimum shifted by one stage predicts the active set
             // better than the clipped unconstrained minimiser (the last stage keeps its own state)
-            if ((prevL | prevU) != 0u) {
-                constexpr unsigned tail = ((1u << NU) - 1u) << (n - NU);
-                const unsigned gl = (prevL >> NU) | (prevL & tail), gu = (prevU >> NU) | (prevU & tail);
-                unsigned own = 0u;
+            if ((prevL | prevU) != 0) {
+                constexpr mask_t tail = ((mask_t(1) << NU) - 1) << (n - NU);
+                const mask_t gl = (prevL >> NU) | (prevL & tail), gu = (prevU >> NU) | (prevU & tail);
+                mask_t own = 0;
 #pragma unroll
-                for (int jb = 0; jb < RB; ++jb) own |= 1u << (jb * LPS + r_or0());
+                for (int jb = 0; jb < RB; ++jb) own |= rowbit(jb);
                 myL = gl & own; myU = gu & own;
             }
             if (pdas(p, myL, myU, todo, 8, gtol, iters)) todo = false;
@@ -623,10 +695,10 @@ struct Spec {
                     for (int jb = 0; jb < RB; ++jb) v[jb] = (st == 2) ? 0.0 : sl[jb] - hh(p, jb);   // interior-point answer
                 }
                 if (p.polish) {
-                    unsigned pl = 0u, pu = 0u;
+                    mask_t pl = 0, pu = 0;
 #pragma unroll
                     for (int jb = 0; jb < RB; ++jb) {
-                        const unsigned bit = 1u << (jb * LPS + r_or0());
+                        const mask_t bit = rowbit(jb);
                         const bool lo = zl[jb] > sl[jb], up = (!lo) && (zu[jb] > su[jb]);
                         if (lo) pl |= bit;
                         if (up) pu |= bit;
@@ -640,8 +712,8 @@ struct Spec {
                 if (!__any(todo) || budget <= 0) break;
             }
         }
-        prevL = inside ? 0u : group_or<LPS>(myL);
-        prevU = inside ? 0u : group_or<LPS>(myU);
+        prevL = inside ? mask_t(0) : gor(myL);
+        prevU = inside ? mask_t(0) : gor(myU);
         return status;
     }
 
@@ -677,7 +749,8 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
     st.lds = lds;
     const int lane = threadIdx.x;
     st.s = lane / LPS; st.r = lane % LPS; st.lane = lane;
-    st.prevL = 0u; st.prevU = 0u;
+    st.prevL = 0; st.prevU = 0;
+    st.pad = (LPS == 64) && (st.r >= n);
     const int r = st.r, s = st.s;
     const long long Bsz = p.Bsz;
     const long long b_raw = (long long)blockIdx.x * SPW + s;
@@ -861,7 +934,7 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
 #pragma unroll
                 for (int uj = 0; uj < NU; ++uj) {
                     const double cu = 0.5 * (sh[p.so.ub + uj] + sh[p.so.lb + uj]);
-                    const double ur = p.has_ref ? sh[p.so.uref + uj * N + bi] : 0.0;
+                    const double ur = p.has_ref ? sh[p.so.uref + uj * N + (bi < N ? bi : N - 1)] : 0.0;   // bi >= N: padding lane
                     tq = __builtin_fma(sh[p.so.R + ui * NU + uj], cu - ur, tq);
                 }
             }
@@ -961,7 +1034,7 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
             double x0[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) { x0[i] = sh[p.so.x0s + i * p.K + k]; st.x[i] = x0[i]; }
-            st.prevL = 0u; st.prevU = 0u;            // unrelated initial states: no carry-over of the active set
+            st.prevL = 0; st.prevU = 0;              // unrelated initial states: no carry-over of the active set
             const int stt = st.solve_qp(p, iters);
             status = stt > status ? stt : status;
             const double vn = value_fn(x0);
@@ -1146,6 +1219,10 @@ static const SpecEntry g_specs[] = {
     SPEC(2, 1, 5, 1),     // C1  (working_example_single.py shape, N = 5)
     SPEC(2, 1, 10, 2),    // C2
     SPEC(4, 2, 10, 4),    // C3  (headline)
+    SPEC(4, 2, 20, 64),   // C4  (n = 40: one matrix row per lane, a whole wave per instance)
+    SPEC(2, 1, 30, 64),   // the reference's N_opc = 30 (V_expert, working_example_multiple.py:35)
+    SPEC(2, 1, 20, 4),    // mpc_test.py:12 (N_open = 20)
+    SPEC(2, 1, 6, 2), SPEC(2, 1, 7, 1), SPEC(2, 1, 8, 2), SPEC(2, 1, 9, 1),   // the reference's horizon sweep 6..10
 };
 
 static const SpecEntry *find_spec(int nx, int nu, int N)

@@ -308,7 +308,7 @@ def test_random_problems(solver, nx, nu, N, warm):
         solver.set_options(warm_start=warm, presolve=warm)
         g1 = solver.solve_batch(N, A, B, Q, R, P, lb, ub, x0, xr, ur)
         g2 = solver.rollout_batch(T, N, A, B, Q, R, P, lb, ub, x0, At, Bt, xr, ur, want_traj=True)
-        assert ("spec" in solver.last_kernel()) == ((nx, nu, N) in [(4, 2, 10), (2, 1, 10), (2, 1, 5)])
+        assert ("spec" in solver.last_kernel()) == ((nx, nu, N) in [(4, 2, 10), (2, 1, 10), (2, 1, 5), (4, 2, 20)])
     finally:
         solver.set_options(warm_start=-1, presolve=-1)
     r1 = orc.solve_batch(N, A, B, Q, R, P, lb, ub, x0, xr, ur)
