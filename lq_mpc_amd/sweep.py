@@ -9,14 +9,16 @@ data_generation that is the MPC hot path:
 The reference issues 57 001 sequential cvxpy solves for this; here every (error level, system) pair
 is one instance of ONE batched launch per horizon, read straight from the reference's .npy files
 (their memory layout already is the library's instance-minor layout, utils_class.py:749-750).
-The scalar bound coefficients alpha/beta/xi (utils_class.py:837-859) are outside the hot path
-(SURVEY.md 8(f) "next") and are not produced here.
+The scalar bound coefficients alpha / beta / xi / bound (utils_class.py:837-859, 920-942) are O(N) host
+formulas per system (lq_mpc_amd/bounds.py); with them data_generation returns, and optionally saves, the
+same 13 arrays as the reference's data_lq_mpc_multipleSys.npz (utils_class.py:944-958).
 """
 import math
 import os
 
 import numpy as np
 
+from . import bounds
 from .mpc import box_from_Fu, default_solver
 
 
@@ -74,7 +76,20 @@ class LQ_RDP_Behavior_Multiple:
     def _s(self):
         return self._solver if self._solver is not None else default_solver()
 
-    def data_generation(self, N_points, ext_radius_max, info_ref, p=None):
+    def _bound_tables(self, N, A_stack, B_stack, e_level, M_V, x_start, V_expert, p):
+        """alpha, beta, xi, bound for a list of models sharing horizon N (utils_class.py:837-859)."""
+        m = A_stack.shape[2]
+        al, be, xi, bd = np.zeros(m), np.zeros(m), np.zeros(m), np.zeros(m)
+        for j in range(m):
+            A, B = A_stack[:, :, j], B_stack[:, :, j]
+            K = dlqr_gain(A, B, self.Q, self.R)
+            ed = bounds.energy_decreasing(N, A, B, self.Q, self.R, self.F_u, e_level[j], e_level[j], -K, M_V[j])
+            eb = bounds.energy_bound(N, A, B, self.Q, self.R, self.lb, self.ub, e_level[j], e_level[j], x_start, p)
+            al[j], be[j], xi[j] = eb["alpha"], eb["beta"], ed["xi"]
+            bd[j] = (al[j] * V_expert + be[j]) / (1 - xi[j] - ed["eta"])
+        return al, be, xi, bd
+
+    def data_generation(self, N_points, ext_radius_max, info_ref, p=None, save_path=None):
         s = self._s()
         nx, nu = self.B_true.shape
         Q, R, lb, ub = self.Q, self.R, self.lb, self.ub
@@ -105,6 +120,22 @@ class LQ_RDP_Behavior_Multiple:
             M_V_horizon[:, i] = s.max_vn_batch(Nh, A4, B4, Q, R, Q, lb, ub, x0_vec)["M_V"]
             true_cost_horizon[:, i] = s.rollout_batch(self.N_mpc, Nh, A4, B4, Q, R, Q, lb, ub, x04,
                                                       self.A_true, self.B_true)["J_T"]
-        return {"error": self.error_vec, "horizon": self.horizon, "V_expert": V_expert,
-                "true_cost_error": true_cost_error, "true_cost_horizon": true_cost_horizon,
-                "M_V_error": M_V_error, "M_V_horizon": M_V_horizon, "x0_vec": x0_vec}
+        out = {"error": self.error_vec, "horizon": self.horizon, "V_expert": V_expert,
+               "true_cost_error": true_cost_error, "true_cost_horizon": true_cost_horizon}
+        if p is not None:
+            # the scalar bound coefficients (host side); the error level of instance (j, i) is error_vec[i]
+            lev = np.tile(self.error_vec, self.N_sys)
+            al, be, xi, bd = self._bound_tables(N, A, B, lev, M_V_error.reshape(-1), x_start, V_expert, p)
+            for k, v in (("alpha", al), ("beta", be), ("xi", xi), ("bound", bd)):
+                out[f"{k}_table_error"] = v.reshape(self.N_sys, n_err)
+            for k in ("alpha", "beta", "xi", "bound"):
+                out[f"{k}_table_horizon"] = np.zeros((self.N_sys, len(self.horizon)))
+            lev4 = np.full(self.N_sys, self.e_nominal)
+            for i, Nh in enumerate(self.horizon):
+                al, be, xi, bd = self._bound_tables(int(Nh), A4, B4, lev4, M_V_horizon[:, i], x_start, V_expert, p)
+                out["alpha_table_horizon"][:, i], out["beta_table_horizon"][:, i] = al, be
+                out["xi_table_horizon"][:, i], out["bound_table_horizon"][:, i] = xi, bd
+            if save_path is not None:
+                np.savez(save_path, **out)                                             # utils_class.py:958
+        out.update({"M_V_error": M_V_error, "M_V_horizon": M_V_horizon, "x0_vec": x0_vec})
+        return out

@@ -250,6 +250,11 @@ def test_data_generation_reproduces_reference_npz(solver, golden_dir):
     assert abs(out["V_expert"] - float(d["V_expert"])) / float(d["V_expert"]) < 1e-10
     assert rel(out["true_cost_error"], d["true_cost_error"]) < 1e-10
     assert rel(out["true_cost_horizon"], d["true_cost_horizon"]) < 1e-10
+    # all 13 arrays of the reference's npz: the bound coefficients are fed with the GPU's M_V and V_expert
+    assert set(d.files) <= set(out)
+    for k in ("xi_table_error", "xi_table_horizon", "alpha_table_error", "alpha_table_horizon",
+              "beta_table_error", "beta_table_horizon", "bound_table_error", "bound_table_horizon"):
+        np.testing.assert_allclose(out[k], d[k], rtol=1e-8, err_msg=k)
     # M_V is not in the npz (only through xi); pin it against the oracle
     eA = np.load(os.path.join(golden_dir, "error_A_f.npy")); eB = np.load(os.path.join(golden_dir, "error_B_f.npy"))
     A = (A0[:, :, None, None] + eA).reshape(2, 2, 1000); B = (B0[:, :, None, None] + eB).reshape(2, 1, 1000)
