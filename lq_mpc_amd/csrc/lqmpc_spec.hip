@@ -1,20 +1,22 @@
-// lqmpc_spec.hip -- register-resident, sub-wavefront-cooperative kernels for the BASELINE configs.
+// lqmpc_spec.hip -- register-resident, lane-cooperative kernels for the BASELINE shapes (the throughput path).
 //
 // Mapping (gfx950, wave64, one wave per 64-thread workgroup, one wave per SIMD):
-//   LPS lanes cooperate on one (A,B) instance ("group"); a wave holds 64/LPS instances.
-//   Row i of the condensed n x n system belongs to lane r = i % LPS of its group, as row-block
-//   jb = i / LPS.  Each lane keeps ITS rows of P = 2(Gamma'Qbar Gamma + Rbar), of the working
-//   matrix K -> L (in-place Cholesky), of Fq = 2 Gamma'Qbar Phi and its slice of every
-//   interior-point vector in VGPRs; all loops are fully unrolled so every register index is a
-//   compile-time constant.  Cross-lane traffic inside a group is DPP quad_perm moves (two
-//   v_mov_b32_dpp per double); nothing is spilled to HBM.  The only LDS use is a transposed,
-//   bank-conflict-free mirror of L (for the column-oriented backward substitution) and the
-//   staging of A^k B during condensing.
+//   LPS lanes cooperate on one (A,B) instance ("group"); a wave holds 64/LPS instances.  Row i of the
+//   condensed n x n system belongs to lane r = i % LPS of its group, as row-block jb = i / LPS.
+//   LPS = 1, 2, 4 (DPP quad_perm groups, n a multiple of LPS, n <= 32) or 64 (one row per lane, n <= 64).
+//   Every loop over rows / columns is fully unrolled so that each register index is a compile-time constant.
+// Storage:
+//   VGPRs  the working matrix K -> L of the in-place Cholesky (own rows) and the solver vectors;
+//   AGPRs  the constant rows of P = 2(Gamma'Qbar Gamma + Rbar), pinned with the "a" constraint (AccArr);
+//   LDS    a column-major XOR-swizzled mirror of L (backward substitution, Cholesky broadcasts), the rows of
+//          Fq = 2 Gamma'Qbar Phi (or G = -P^-1 Fq with the presolve), and A^m B while condensing.
+// Cross-lane traffic: v_mov_b32_dpp / v_readlane for the latency-critical values, group-uniform ds_read_b128
+//   for the rest.  HBM sees the inputs (A, B, x0) and the results, nothing else.
+// Algorithm (Spec::solve_qp): presolve -> primal-dual active-set warm start -> staged Mehrotra
+//   predictor-corrector interior point with active-set finishing.
 //
-// Per-instance HBM traffic is exactly the algorithmic bytes: A, B, x0 in, results out.
-//
-// Restates /root/reference/utils_class.py:48-91 (solve) and 245-285 (simulate); the
-// interior-point method replaces cvxpy's QP back-end (utils_class.py:84-88).
+// Restates /root/reference/utils_class.py:48-91 (solve) and 245-285 (simulate); the solver replaces cvxpy's
+// QP back-end (utils_class.py:84-88).
 #include "lqmpc_common.h"
 
 #include <type_traits>
@@ -194,11 +196,6 @@ struct Spec {
         // LPS > 1: all own rows belong to input r % NU (LPS is a multiple of NU); two cached loads, no register kept
         const int k = (LPS == 1) ? jb % NU : r % NU;
         return 0.5 * (p.sh[p.so.ub + k] - p.sh[p.so.lb + k]);
-    }
-    __device__ __forceinline__ double cc(const KParams &p, int jb) const
-    {
-        const int k = (LPS == 1) ? jb % NU : r % NU;
-        return 0.5 * (p.sh[p.so.ub + k] + p.sh[p.so.lb + k]);
     }
 
     // ---- in-place Cholesky of the row-distributed matrix in a[] (right-looking, column k) ----
