@@ -67,9 +67,12 @@ enum lqmpc_error {
 
 /* Which kernel family runs the batch. */
 enum lqmpc_kernel {
-    LQMPC_KERNEL_AUTO = 0,       /* register-resident specialisation when built for (nx,nu,N), else generic */
-    LQMPC_KERNEL_GENERIC = 1,    /* any dims up to the limits; one instance per lane, workspace in HBM */
-    LQMPC_KERNEL_SPECIALIZED = 2 /* fail with LQMPC_ERR_UNSUPPORTED if no specialisation exists */
+    LQMPC_KERNEL_AUTO = 0,        /* register-resident specialisation when built for (nx,nu,N); else the workgroup
+                                     kernel when it applies; else generic */
+    LQMPC_KERNEL_GENERIC = 1,     /* any dims up to the limits; one instance per lane, workspace in HBM */
+    LQMPC_KERNEL_SPECIALIZED = 2, /* fail with LQMPC_ERR_UNSUPPORTED if no specialisation exists */
+    LQMPC_KERNEL_WORKGROUP = 3    /* one instance per 256-thread workgroup, matrices in LDS (32 < N*nu <= 128, nx <= 16,
+                                     zero references, symmetric box); LQMPC_ERR_UNSUPPORTED otherwise */
 };
 
 typedef struct lqmpc_options {

@@ -34,7 +34,7 @@ class Options(ctypes.Structure):
                 ("presolve", ctypes.c_int32), ("order", ctypes.c_int32), ("warm_start", ctypes.c_int32)]
 
 
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_SPECIALIZED = 0, 1, 2
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_SPECIALIZED, KERNEL_WORKGROUP = 0, 1, 2, 3
 
 
 class LqmpcError(RuntimeError):

@@ -17,6 +17,9 @@ void launch_generic(const KParams &p, hipStream_t stream);
 // lqmpc_spec.hip: returns false when no specialisation is built for (nx,nu,N)
 bool spec_available(int nx, int nu, int N);
 bool launch_spec(const KParams &p, hipStream_t stream, const char **name);
+// lqmpc_wg.hip: one instance per workgroup, 32 < n <= 128
+bool wg_supported(const KParams &p, const double *lb, const double *ub);
+bool launch_wg(const KParams &p, hipStream_t stream, const char **name);
 }  // namespace lqmpc
 
 using lqmpc::KParams;
@@ -52,6 +55,7 @@ struct lqmpc_handle {
     std::vector<double> shared_host; // last uploaded shared block
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const char *last_kernel = "none";
+    bool use_wg = false;             // set by prepare(): this call runs on the workgroup kernel
 };
 
 static int ensure(lqmpc_handle *h, DevBuf &b, size_t bytes)
@@ -157,7 +161,7 @@ int lqmpc_set_options(lqmpc_handle *h, const lqmpc_options *opt)
     if (!(opt->tau > 0.0 && opt->tau < 1.0)) return fail(LQMPC_ERR_BAD_ARG, "tau must be in (0,1)");
     if (!(opt->z0_scale > 0.0)) return fail(LQMPC_ERR_BAD_ARG, "z0_scale must be positive");
     if (opt->max_iter < 1 || opt->max_iter > 1000) return fail(LQMPC_ERR_BAD_ARG, "max_iter must be in [1,1000]");
-    if (opt->kernel < LQMPC_KERNEL_AUTO || opt->kernel > LQMPC_KERNEL_SPECIALIZED) return fail(LQMPC_ERR_BAD_ARG, "unknown kernel selector");
+    if (opt->kernel < LQMPC_KERNEL_AUTO || opt->kernel > LQMPC_KERNEL_WORKGROUP) return fail(LQMPC_ERR_BAD_ARG, "unknown kernel selector");
     if (opt->presolve < -1 || opt->presolve > 1) return fail(LQMPC_ERR_BAD_ARG, "presolve must be -1, 0 or 1");
     if (opt->order < -1 || opt->order > 1) return fail(LQMPC_ERR_BAD_ARG, "order must be -1, 0 or 1");
     if (opt->warm_start < -1 || opt->warm_start > 1) return fail(LQMPC_ERR_BAD_ARG, "warm_start must be -1, 0 or 1");
@@ -193,7 +197,7 @@ static int check_dims(int nx, int nu, int N, int64_t Bsz)
 
 static bool use_spec(const lqmpc_handle *h, int nx, int nu, int N)
 {
-    return h->opt.kernel != LQMPC_KERNEL_GENERIC && lqmpc::spec_available(nx, nu, N);
+    return h->opt.kernel != LQMPC_KERNEL_GENERIC && h->opt.kernel != LQMPC_KERNEL_WORKGROUP && lqmpc::spec_available(nx, nu, N);
 }
 
 struct Call {
@@ -252,7 +256,11 @@ static int prepare(lqmpc_handle *h, const Call &c, KParams &p)
     p.sh = (const double *)h->shared.p;
     if (h->opt.kernel == LQMPC_KERNEL_SPECIALIZED && !lqmpc::spec_available(nx, nu, N))
         return fail(LQMPC_ERR_UNSUPPORTED, "no register-resident specialisation built for these dims");
-    if (!use_spec(h, nx, nu, N)) {
+    h->use_wg = !use_spec(h, nx, nu, N) && (h->opt.kernel == LQMPC_KERNEL_AUTO || h->opt.kernel == LQMPC_KERNEL_WORKGROUP) &&
+                lqmpc::wg_supported(p, c.lb, c.ub);
+    if (h->opt.kernel == LQMPC_KERNEL_WORKGROUP && !h->use_wg)
+        return fail(LQMPC_ERR_UNSUPPORTED, "the workgroup kernel needs 32 < N*nu <= 128, nx <= 16, zero references, lb = -ub");
+    if (!use_spec(h, nx, nu, N) && !h->use_wg) {
         p.ws_stride = (c.Bsz + 63) / 64 * 64;
         const size_t bytes = (size_t)lqmpc::generic_ws_entries(nx, nu, N) * (size_t)p.ws_stride * sizeof(double);
         rc = ensure(h, h->ws, bytes);
@@ -306,6 +314,8 @@ static int launch(lqmpc_handle *h, const KParams &p)
     const char *name = "lqmpc_generic_kernel";
     if (use_spec(h, p.nx, p.nu, p.N)) {
         if (!lqmpc::launch_spec(p, h->stream, &name)) return fail(LQMPC_ERR_UNSUPPORTED, "specialisation launch failed");
+    } else if (h->use_wg) {
+        if (!lqmpc::launch_wg(p, h->stream, &name)) return fail(LQMPC_ERR_HIP, "workgroup kernel launch failed");
     } else {
         lqmpc::launch_generic(p, h->stream);
     }
