@@ -14,8 +14,9 @@
 // G x inside the box -> done), primal-dual active-set iterations warm-started from the previous step's
 // face, Mehrotra interior point in stages with active-set finishing as the fallback.
 //
-// Restriction of this first version: zero references and a symmetric box (every BASELINE config); other
-// problems of this size go to the generic kernel.
+// References and asymmetric boxes enter as in the other kernels: u = v + centre, |v| <= h, and the constant
+// part of the linear term qr = 2 gref + P centre (gref by a costate recursion on vectors) shifts the
+// unconstrained minimiser by v_r = -P^-1 qr.
 #include "lqmpc_wg_linalg.h"
 #include <cstdio>
 
@@ -55,9 +56,8 @@ size_t wg_lds_bytes(int nx, int nu, int N) { return (size_t)wg_offsets(nx, nu, N
 
 bool wg_supported(const KParams &p, const double *lb, const double *ub)
 {
-    if (p.n <= 32 || p.n > 128 || p.nx > 16 || p.has_ref) return false;
-    for (int k = 0; k < p.nu; ++k)
-        if (lb[k] != -ub[k]) return false;
+    (void)lb; (void)ub;
+    if (p.n <= 32 || p.n > 128 || p.nx > 16) return false;
     return wg_lds_bytes(p.nx, p.nu, p.N) <= 160 * 1024;
 }
 
@@ -98,7 +98,7 @@ struct Wg {
     double *lds;
     int n, nb, np, nx, nu, N, t;
     double preg[PREG];        // my share of P (flat index t + 256 m over the block image)
-    double h;                 // half-width of my row's input (row < n), 1 otherwise
+    double h, ctr, vr;        // half-width and centre of my row's input box (row < n; 1, 0 otherwise); v_r of my row
     bool own;                 // this thread owns row t (t < n)
     // solver state of my row
     double sl, su, zl, zu, rd, v, qs, act_prev;
@@ -287,12 +287,54 @@ struct Wg {
             if (own) G[t * nx + a] = -lds[o.vb + t];
             __syncthreads();
         }
+        // constant part of the linear term: qr = 2 gref + P centre, with
+        //   d_r = -xref_r,  lam_r = Q_r d_r + A' lam_{r+1},  gref_r = B' lam_r - R uref_r   (columns r = 0..N-1 <-> x_{r+1}, u_r)
+        double *gq = lds + o.vw;
+        if (t < np) gq[t] = 0.0;
+        if (p.has_ref) {
+            const double *xr = sh + p.so.xref, *ur = sh + p.so.uref;
+            double *lam = Lam, *lam2 = Lam + nx;
+            if (t < nx) lam[t] = 0.0;
+            for (int r = N - 1; r >= 0; --r) {
+                const double *Qr = sh + ((r < N - 1) ? p.so.Q : p.so.P);
+                __syncthreads();
+                if (t < nx) {
+                    double a = 0.0;
+                    for (int y = 0; y < nx; ++y) a = __builtin_fma(Qr[t * nx + y], -xr[y * N + r], a);
+                    for (int y = 0; y < nx; ++y) a = __builtin_fma(Xf[y * nx + t], lam[y], a);
+                    lam2[t] = a;
+                }
+                __syncthreads();
+                if (t < nx) lam[t] = lam2[t];
+                if (t < nu) {
+                    double a = 0.0;
+                    for (int x = 0; x < nx; ++x) a = __builtin_fma(M[x * nu + t], lam2[x], a);
+                    for (int j = 0; j < nu; ++j) a = __builtin_fma(-sh[p.so.R + t * nu + j], ur[j * N + r], a);
+                    gq[r * nu + t] = 2.0 * a;
+                }
+            }
+            __syncthreads();
+        }
+        const double gref2 = (t < np) ? gq[t] : 0.0;
+        __syncthreads();
+        if (t < np) gq[t] = own ? ctr : 0.0;
+        load_K(false, 0.0);
+        const double qr = gref2 + symv_row(gq);
+        vr = 0.0;
+        if (block_any(own && qr != 0.0)) {
+            __syncthreads();
+            if (t < np) lds[o.vb + t] = own ? qr : 0.0;
+            factor();
+            solve_vb();
+            vr = own ? -lds[o.vb + t] : 0.0;
+            __syncthreads();
+        }
     }
 
     // v_unc = G x for my row (x in LDS at o.xs)
     __device__ __forceinline__ double vunc() const
     {
-        double s = 0.0;
+        double s = own ? vr : 0.0;
         if (own) for (int a = 0; a < nx; ++a) s = __builtin_fma(lds[o.G + t * nx + a], lds[o.xs + a], s);
         return s;
     }
@@ -440,7 +482,9 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
     const int nx = p.nx, nu = p.nu, N = p.N, n = p.n;
     Wg w{p, wg_offsets(nx, nu, N), lds, n, (n + BS - 1) / BS, ((n + BS - 1) / BS) * BS, nx, nu, N, t};
     w.own = t < n;
-    w.h = w.own ? p.sh[p.so.ub + t % nu] : 1.0;
+    w.h = w.own ? 0.5 * (p.sh[p.so.ub + t % nu] - p.sh[p.so.lb + t % nu]) : 1.0;
+    w.ctr = w.own ? 0.5 * (p.sh[p.so.ub + t % nu] + p.sh[p.so.lb + t % nu]) : 0.0;
+    w.vr = 0.0;
     w.act_prev = 0.0; w.v = 0.0; w.qs = 0.0; w.sl = w.su = w.zl = w.zu = 1.0; w.rd = 0.0;
     w.setup(b);
     const double *sh = p.sh;
@@ -449,10 +493,10 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
         if (t < nx) xs[t] = p.rec ? p.rec[b * (nx * nx + nx * nu + nx) + nx * nx + nx * nu + t] : p.x0[(long long)t * Bsz + b];
         __syncthreads();
     };
-    // u_k of stage i after a solve: v of row i*nu + k (symmetric box: centre 0), clipped
+    // u_k of stage i after a solve: clipped v of row i*nu + k, plus the centre of the box
     auto publish_v = [&]() {
         __syncthreads();
-        if (t < w.np) lds[w.o.vw + t] = w.own ? fmin(fmax(w.v, -w.h), w.h) : 0.0;
+        if (t < w.np) lds[w.o.vw + t] = w.own ? fmin(fmax(w.v, -w.h), w.h) + w.ctr : 0.0;
         __syncthreads();
     };
     int iters = 0, status = 0;
@@ -473,9 +517,13 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
                 }
                 const int oQ = (s < N - 1) ? p.so.Q : p.so.P;
                 for (int i = 0; i < nx; ++i) xsv[i] = xn[i];
+                if (p.has_ref) for (int i = 0; i < nx; ++i) xn[i] -= sh[p.so.xref + i * N + s];
                 for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) cost = __builtin_fma(xn[i] * sh[oQ + i * nx + j], xn[j], cost);
-                for (int k = 0; k < nu; ++k) for (int j = 0; j < nu; ++j)
-                    cost = __builtin_fma(lds[w.o.vw + s * nu + k] * sh[p.so.R + k * nu + j], lds[w.o.vw + s * nu + j], cost);
+                for (int k = 0; k < nu; ++k) for (int j = 0; j < nu; ++j) {
+                    const double dk = lds[w.o.vw + s * nu + k] - (p.has_ref ? sh[p.so.uref + k * N + s] : 0.0);
+                    const double dj = lds[w.o.vw + s * nu + j] - (p.has_ref ? sh[p.so.uref + j * N + s] : 0.0);
+                    cost = __builtin_fma(dk * sh[p.so.R + k * nu + j], dj, cost);
+                }
             }
         }
         return cost;

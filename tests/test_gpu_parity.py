@@ -290,15 +290,21 @@ def test_difficulty_ordering_is_transparent(solver, golden_dir):
 
 
 # ---------------- stress: random shapes of cost, box, conditioning on the specialised shapes ----------------
-@pytest.mark.parametrize("nx,nu,N", [(4, 2, 10), (2, 1, 10), (2, 1, 5), (3, 2, 6), (1, 1, 1), (5, 3, 4), (4, 2, 20)])
+WG_SHAPES = [(8, 4, 30), (6, 3, 15), (16, 2, 17), (3, 2, 64), (5, 1, 33)]     # n = 120, 45, 34, 128, 33
+
+
+@pytest.mark.parametrize("nx,nu,N", [(4, 2, 10), (2, 1, 10), (2, 1, 5), (3, 2, 6), (1, 1, 1), (5, 3, 4), (4, 2, 20)] + WG_SHAPES)
 @pytest.mark.parametrize("warm", [0, 1])
 def test_random_problems(solver, nx, nu, N, warm):
     """Unstable / badly scaled models, dense Q/R/P, asymmetric boxes, references, per-instance plants, on the
-    specialised shapes (warm start on / off) and on shapes only the generic kernel covers."""
+    specialised shapes (warm start on / off), on shapes only the generic kernel covers, and on the
+    one-instance-per-workgroup shapes (32 < n <= 128, including stages that straddle the 16-row blocks)."""
     rng = np.random.default_rng(100 * nx + N + warm)
-    Bsz, T = 768, 12
+    wg = (nx, nu, N) in WG_SHAPES
+    Bsz, T = (96, 6) if wg else (768, 12)
     A = rng.standard_normal((nx, nx, Bsz))
-    A *= rng.uniform(0.3, 1.3, Bsz) / np.abs(np.linalg.eigvals(A.transpose(2, 0, 1))).max(axis=1)      # spectral radius in [0.3, 1.3]
+    rho_hi = 1.3 if N <= 20 else 200.0 ** (1.0 / N)           # keeps rho^N (the conditioning of the condensed Hessian) bounded
+    A *= rng.uniform(0.3, rho_hi, Bsz) / np.abs(np.linalg.eigvals(A.transpose(2, 0, 1))).max(axis=1)   # spectral radius in [0.3, rho_hi]
     B = rng.standard_normal((nx, nu, Bsz)) * rng.uniform(0.1, 2.0, (1, 1, Bsz))
     def spd(m, lo, hi):
         M = rng.standard_normal((m, m)); M = M @ M.T / m + np.eye(m)
@@ -316,6 +322,7 @@ def test_random_problems(solver, nx, nu, N, warm):
         g1 = solver.solve_batch(N, A, B, Q, R, P, lb, ub, x0, xr, ur)
         g2 = solver.rollout_batch(T, N, A, B, Q, R, P, lb, ub, x0, At, Bt, xr, ur, want_traj=True)
         assert ("spec" in solver.last_kernel()) == ((nx, nu, N) in [(4, 2, 10), (2, 1, 10), (2, 1, 5), (4, 2, 20)])
+        assert ("wg" in solver.last_kernel()) == wg
     finally:
         solver.set_options(warm_start=-1, presolve=-1)
     r1 = orc.solve_batch(N, A, B, Q, R, P, lb, ub, x0, xr, ur)
@@ -344,3 +351,29 @@ def test_status_reports_iteration_cap(solver):
             solver.set_options(eps=2.0)
     finally:
         solver.set_options(kernel=KERNEL_AUTO, warm_start=-1, presolve=-1, polish=1, max_iter=50, eps=1e-12)
+
+
+# ---------------- the one-instance-per-workgroup kernel (32 < n <= 128) ----------------
+def test_workgroup_kernel_dispatch_and_agreement(solver):
+    """C5 goes to the workgroup kernel by default; forced on C4's dims it agrees with the register-resident
+    specialisation and with the generic kernel; out of its range it refuses instead of falling back."""
+    from lq_mpc_amd._lib import KERNEL_WORKGROUP
+    b5, b4, b3 = synth.make_batch(5, Bsz=48), synth.make_batch(4, Bsz=96), synth.make_batch(3, Bsz=8)
+    try:
+        g5 = solver.rollout_batch(5, *args(b5), b5["x0"], b5["A_true"], b5["B_true"], want_traj=True)
+        assert solver.last_kernel() == "lqmpc_wg_kernel"
+        solver.set_options(kernel=KERNEL_GENERIC)
+        r5 = solver.rollout_batch(5, *args(b5), b5["x0"], b5["A_true"], b5["B_true"], want_traj=True)
+        assert solver.last_kernel() == "lqmpc_generic_kernel"
+        assert rel(g5["J_T"], r5["J_T"]) < TIGHT and u_err(g5["U"], r5["U"]) < RTOL
+        solver.set_options(kernel=KERNEL_AUTO)
+        s4 = solver.solve_batch(*args(b4), b4["x0"])
+        assert "spec" in solver.last_kernel()
+        solver.set_options(kernel=KERNEL_WORKGROUP)
+        w4 = solver.solve_batch(*args(b4), b4["x0"])
+        assert solver.last_kernel() == "lqmpc_wg_kernel"
+        assert rel(w4["V_N"], s4["V_N"]) < TIGHT and u_err(w4["u_0"], s4["u_0"]) < RTOL
+        with pytest.raises(Exception, match="workgroup"):
+            solver.solve_batch(*args(b3), b3["x0"])             # n = 20: below the kernel's range
+    finally:
+        solver.set_options(kernel=KERNEL_AUTO)
