@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--bsz", type=int, default=0, help="systems per GPU (default: the config's)")
     ap.add_argument("--T", type=int, default=0, help="rollout length (default: the config's, 30)")
     ap.add_argument("--mode", choices=["rollout", "oneshot"], default="rollout")
-    ap.add_argument("--kernel", choices=["auto", "generic", "specialized"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "generic", "specialized", "workgroup"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (box share: 16 per GPU)")
     ap.add_argument("--no-oneshot", action="store_true", help="skip the extra one-shot measurement")
@@ -99,7 +99,7 @@ def main():
     from lq_mpc_amd import dist as ld
 
     stream = torch.cuda.current_stream(dev).cuda_stream
-    kern = {"auto": 0, "generic": 1, "specialized": 2}[args.kernel]
+    kern = {"auto": 0, "generic": 1, "specialized": 2, "workgroup": 3}[args.kernel]
     s = BatchSolver(local_rank, stream=stream, kernel=kern)
     s.reserve(nx, nu, N, Bsz, T)
 

@@ -4,19 +4,28 @@
 //   registers  the constant matrix P = 2(Gamma'Qbar Gamma + Rbar): the lower block triangle of 16x16
 //              blocks, 39 doubles per thread (flat over the workgroup, same order as the LDS image);
 //              one element of every solver vector per thread (thread i <-> row i);
-//   LDS        the working matrix K -> L (same block layout), the inverses of L's diagonal blocks,
-//              G = -P^-1 Fq (n x nx), two work vectors, the active-set flags, A^m B while condensing.
+//   LDS        W = P^-1 in the same block layout (the matrix every step works with), G = -W Fq (n x nx),
+//              the batch-shared data (Q, R, P_T, box, references, plant), a small workspace for the
+//              active-set systems, work vectors, A^m B while condensing;
 //   HBM        inputs and results only.
-// Linear algebra: lqmpc_wg_linalg.h -- blocked Cholesky whose panel and trailing updates are 16x16x16
-// products on v_mfma_f64_16x16x4_f64 (the one place of this path that is a dense contraction), blocked
-// substitution with the inverted diagonal blocks.
-// Algorithm per QP (same as the other kernels): presolve (unconstrained minimiser
-// G x inside the box -> done), primal-dual active-set iterations warm-started from the previous step's
-// face, Mehrotra interior point in stages with active-set finishing as the fallback.
+// Linear algebra: lqmpc_wg_linalg.h -- blocked Cholesky, triangular inverse and Z'Z whose block products run
+// on v_mfma_f64_16x16x4_f64 (the one place of this path that is a dense contraction); condensing and
+// G = -W Fq are block products on the same instruction.
+//
+// Algorithm per QP.  Same iterates as the primal-dual active-set method of the other
+// kernels, but solved from the dual side because P is constant per instance and the active set is small:
+//   v_unc = G x + v_r;  inside the box -> done (presolve);
+//   active set A with signs s (warm start: the previous step's set shifted by one stage):
+//       (W_AA) lam = v_unc,A - s h_A,   v = v_unc - W[:,A] lam,   gradient on A = -lam, zero elsewhere,
+//   i.e. an m x m system (m = |A|, gathered from W) instead of an n x n one; update A from the signs of lam
+//   and the box violations of v; repeat until A is stable.
+// If A outgrows the workspace or the iteration cycles, the QP goes through the staged interior-point method
+// with primal active-set finishing (n x n factorisations in the W region, P from registers), after which W
+// is rebuilt.
 //
 // References and asymmetric boxes enter as in the other kernels: u = v + centre, |v| <= h, and the constant
 // part of the linear term qr = 2 gref + P centre (gref by a costate recursion on vectors) shifts the
-// unconstrained minimiser by v_r = -P^-1 qr.
+// unconstrained minimiser by v_r = -W qr.
 #include "lqmpc_wg_linalg.h"
 #include <cstdio>
 
@@ -24,10 +33,25 @@ namespace lqmpc {
 
 using namespace wg;
 
+#ifdef LQMPC_WG_PROF
+__device__ long long g_wg_prof[16];
+#define PROF(k) do { const long long now_ = clock64(); if (threadIdx.x == 0 && blockIdx.x == 0) g_wg_prof[k] += now_ - prof_t; prof_t = clock64(); } while (0)
+#define PROF_START long long prof_t = clock64()
+#else
+#define PROF(k) do { } while (0)
+#define PROF_START do { } while (0)
+#endif
+
 constexpr int PREG = 39;                 // ceil(36 blocks * 272 doubles / 256 threads)
+constexpr int LDS_DOUBLES = 160 * 1024 / 8 - 8;
 
 struct WgOff {                            // LDS offsets in doubles
-    int K, Linv, G, vb, vw, act, red, xs, M, PM, DM, Xf, Lam, total;
+    int K, Linv, G, vb, vw, act, lam, list, red, xs, AB, SH, shn;
+    int U;                                // union: condensing scratch | active-set workspace | state trajectory
+    int X, Xf, Lam;                       //   condensing: a block-row matrix (Q M | P_T M | Fq), A^k, costate
+    int T, S, smax;                       //   scratch block, gathered system (smax x smax blocks at most)
+    int Xs;                               //   predicted states for V_N
+    int total;
 };
 
 __host__ __device__ inline WgOff wg_offsets(int nx, int nu, int N)
@@ -36,19 +60,29 @@ __host__ __device__ inline WgOff wg_offsets(int nx, int nu, int N)
     WgOff o;
     int c = 0;
     o.K = c;    c += nb * (nb + 1) / 2 * BLK;
-    o.Linv = c; c += nb * BLK;
+    o.Linv = c; c += nb * BLK;             // also the block-row image of the A^m B while condensing
     o.G = c;    c += np * nx;
     o.vb = c;   c += np;
     o.vw = c;   c += np;
     o.act = c;  c += np;
+    o.lam = c;  c += np;
+    o.list = c; c += np / 2;
     o.red = c;  c += 16;
     o.xs = c;   c += 2 * nx + 8;
-    o.M = c;    c += N * nx * nu;
-    o.PM = c;   c += N * nx * nu;
-    o.DM = c;   c += N * nx * nu;
-    o.Xf = c;   c += (N + 1) * nx * nx;
-    o.Lam = c;  c += 2 * nx * nx;
-    o.total = c;
+    o.AB = c;   c += nx * nx + nx * nu;
+    o.shn = 3 * nx * nx + nu * nu + 2 * nu + (nx + nu) * N + nx * nu;     // everything of the shared block before x0s
+    o.SH = c;   c += o.shn + (o.shn & 1);
+    o.U = c;
+    o.X = c; o.Xf = o.X + nb * BLK; o.Lam = o.Xf + N * nx * nx;
+    int usize = o.Lam + 2 * nx * nx - o.U;
+    o.T = c; o.S = c + BLK; o.Xs = c;
+    int smax = 0;
+    while (smax < nb && o.U + ((smax + 1) * (smax + 2) / 2 + 1) * BLK <= LDS_DOUBLES) ++smax;
+    o.smax = smax;
+    const int ssize = (smax * (smax + 1) / 2 + 1) * BLK;
+    if (ssize > usize) usize = ssize;
+    if ((N + 1) * nx > usize) usize = (N + 1) * nx;
+    o.total = o.U + usize;
     return o;
 }
 
@@ -58,7 +92,8 @@ bool wg_supported(const KParams &p, const double *lb, const double *ub)
 {
     (void)lb; (void)ub;
     if (p.n <= 32 || p.n > 128 || p.nx > 16) return false;
-    return wg_lds_bytes(p.nx, p.nu, p.N) <= 160 * 1024;
+    const WgOff o = wg_offsets(p.nx, p.nu, p.N);
+    return o.total <= LDS_DOUBLES && o.smax >= 1;
 }
 
 // ---- workgroup reductions over the threads that own a row (others pass the neutral element) ----
@@ -74,7 +109,7 @@ __device__ __forceinline__ double wave_max(double x)
     for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o));
     return x;
 }
-__device__ __forceinline__ double block_sum(double x, double *red)
+__device__ __forceinline__ double block_sum(double x, ldsd *red)
 {
     x = wave_sum(x);
     __syncthreads();
@@ -82,7 +117,7 @@ __device__ __forceinline__ double block_sum(double x, double *red)
     __syncthreads();
     return red[0] + red[1] + red[2] + red[3];
 }
-__device__ __forceinline__ double block_max(double x, double *red)
+__device__ __forceinline__ double block_max(double x, ldsd *red)
 {
     x = wave_max(x);
     __syncthreads();
@@ -92,10 +127,34 @@ __device__ __forceinline__ double block_max(double x, double *red)
 }
 __device__ __forceinline__ bool block_any(bool f) { return __syncthreads_or(f ? 1 : 0) != 0; }
 
+// acc + sum_{y<len} a[y*sa] * b[y*sb] for short runtime lengths (nx, nu <= 16): loads issued eight / four at a
+// time so that their LDS latencies overlap instead of adding up
+__device__ __forceinline__ double ldot(const ldsd *a, int sa, const ldsd *b, int sb, int len, double acc = 0.0)
+{
+    int y = 0;
+    for (; y + 8 <= len; y += 8) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { av[k] = a[(y + k) * sa]; bv[k] = b[(y + k) * sb]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = __builtin_fma(av[k], bv[k], acc);
+    }
+    if (y + 4 <= len) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { av[k] = a[(y + k) * sa]; bv[k] = b[(y + k) * sb]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = __builtin_fma(av[k], bv[k], acc);
+        y += 4;
+    }
+    for (; y < len; ++y) acc = __builtin_fma(a[y * sa], b[y * sb], acc);
+    return acc;
+}
+
 struct Wg {
     const KParams &p;
     WgOff o;
-    double *lds;
+    ldsd *lds;
     int n, nb, np, nx, nu, N, t;
     double preg[PREG];        // my share of P (flat index t + 256 m over the block image)
     double h, ctr, vr;        // half-width and centre of my row's input box (row < n; 1, 0 otherwise); v_r of my row
@@ -103,7 +162,8 @@ struct Wg {
     // solver state of my row
     double sl, su, zl, zu, rd, v, qs, act_prev;
 
-    __device__ __forceinline__ int *flag() { return (int *)(lds + o.red + 8); }
+    __device__ __forceinline__ ldsi *flag() { return (ldsi *)(lds + o.red + 8); }
+    __device__ __forceinline__ const ldsd *shd() const { return lds + o.SH; }      // the batch-shared block, staged in LDS
 
     // element (i, j) of flat index e in the block image; false for the padding column / rows outside
     __device__ __forceinline__ bool decode(int e, int &i, int &j) const
@@ -115,10 +175,11 @@ struct Wg {
         i = ib * BS + r; j = jb * BS + c;
         return c < BS && ib < nb;
     }
-    __device__ __forceinline__ double *kaddr(int i, int j) const      // (i, j) with j's block <= i's block
+    __device__ __forceinline__ ldsd *kaddr(int i, int j) const      // (i, j) with j's block <= i's block
     {
         return lds + o.K + blk_index(i / BS, j / BS) * BLK + (i % BS) * LD + (j % BS);
     }
+    __device__ __forceinline__ double wsym(int i, int j) const { return (i / BS >= j / BS) ? *kaddr(i, j) : *kaddr(j, i); }
 
     // K <- P (+ dg on my diagonal element when add_diag)
     __device__ __forceinline__ void load_K(bool add_diag, double dg)
@@ -137,7 +198,7 @@ struct Wg {
     __device__ __forceinline__ void mask_K()
     {
         const int cnt = nb * (nb + 1) / 2 * BLK;
-        const double *act = lds + o.act;
+        const ldsd *act = lds + o.act;
 #pragma unroll
         for (int m = 0; m < PREG; ++m) {
             const int e = t + THREADS * m;
@@ -148,19 +209,19 @@ struct Wg {
         }
         __syncthreads();
     }
-    // y_t = (P w)_t from the unfactored image of P in K (w: LDS vector of np doubles)
-    __device__ __forceinline__ double symv_row(const double *w) const
+    // y_t = (M w)_t for the symmetric matrix whose image is in K (w: LDS vector of np doubles)
+    __device__ __forceinline__ double symv_row(const ldsd *w) const
     {
         double acc = 0.0;
         if (t < np) {
             const int ib = t / BS, r = t % BS;
             for (int jb = 0; jb <= ib; ++jb) {                    // row t, blocks left of and on the diagonal (full block stored)
-                const double *B = lds + o.K + blk_index(ib, jb) * BLK + r * LD;
+                const ldsd *B = lds + o.K + blk_index(ib, jb) * BLK + r * LD;
 #pragma unroll
                 for (int c = 0; c < BS; ++c) acc = __builtin_fma(B[c], w[jb * BS + c], acc);
             }
             for (int kb = ib + 1; kb < nb; ++kb) {                // column t of the blocks below
-                const double *B = lds + o.K + blk_index(kb, ib) * BLK + r;
+                const ldsd *B = lds + o.K + blk_index(kb, ib) * BLK + r;
 #pragma unroll
                 for (int c = 0; c < BS; ++c) acc = __builtin_fma(B[c * LD], w[kb * BS + c], acc);
             }
@@ -170,79 +231,141 @@ struct Wg {
     __device__ __forceinline__ bool factor() { return chol_blocked(lds + o.K, lds + o.Linv, nb, flag()); }
     __device__ __forceinline__ void solve_vb() { solve_blocked(lds + o.K, lds + o.Linv, nb, lds + o.vb); }
 
+    // K region: P -> W = P^-1.  Cholesky, inverse of the factor, Z'Z; all block products on the MFMA.
+    __device__ __forceinline__ bool make_W(bool reload)
+    {
+        PROF_START;
+        if (reload) load_K(false, 0.0);
+        const bool ok = factor();
+        PROF(8);
+        tri_invert_blocked(lds + o.K, lds + o.Linv, nb);
+        PROF(9);
+        ztz_blocked(lds + o.K, nb);
+        PROF(10);
+        return ok;
+    }
+
+    // rows of the block-row matrix Y (np x 16, block layout) <- W_T * (rows of Ma), W_T an nx x nx weight in LDS
+    __device__ __forceinline__ void weight_rows(const ldsd *Ma, const ldsd *Wt, ldsd *Y)
+    {
+        if (t < np) {
+            const ldsd *src = Ma + (t / BS) * BLK + (t % BS) * LD;
+            ldsd *dst = Y + (t / BS) * BLK + (t % BS) * LD;
+            for (int x = 0; x < nx; ++x) dst[x] = ldot(Wt + x * nx, 1, src, 1, nx);
+        }
+    }
+
     // ---------------- condensing (utils_class.py:62-75 in matrix form) ----------------
-    __device__ void setup(long long b)
+    // Row i = bi*nu + ui of Gamma'... belongs to stage bi; with a = N-1-bi "stages to go" and M_a = A^a B,
+    //   H(i, j) = M_a' P_T M_b + sum_{s>=1} M_{a-s}' Q M_{b-s}
+    //           = C1(i, j) + sum_{s>=1} Cq(i + s nu, j + s nu),   C1 = Ma (P_T Ma)', Cq = Ma (Q Ma)',
+    // with Ma the n x nx matrix whose row i is column ui of M_a: two block-row products on the MFMA and a
+    // suffix sum along the stage diagonals.
+    __device__ __forceinline__ void setup(long long b)
     {
         const long long Bsz = p.Bsz;
-        const double *sh = p.sh;
-        double *M = lds + o.M, *PM = lds + o.PM, *DM = lds + o.DM, *Xf = lds + o.Xf, *Lam = lds + o.Lam;
-        const double *A = p.rec ? nullptr : p.A;
-        auto ldA = [&](int e) { return p.rec ? p.rec[b * (nx * nx + nx * nu + nx) + e] : A[(long long)e * Bsz + b]; };
-        auto ldB = [&](int e) { return p.rec ? p.rec[b * (nx * nx + nx * nu + nx) + nx * nx + e] : p.B[(long long)e * Bsz + b]; };
-        // A into Xf[0] (scratch for A itself: Xf block 0 holds A, blocks k >= 1 hold A^k), B into M[0]
-        for (int e = t; e < nx * nx; e += THREADS) Xf[e] = ldA(e);
-        for (int e = t; e < nx * nu; e += THREADS) M[e] = ldB(e);
-        __syncthreads();
-        // M[m] = A M[m-1];  Xf[k] = A Xf[k-1]  (A^1 = A is Xf[0] shifted: keep A in Xf[0], A^k in Xf[k-1])
-        for (int m = 1; m < N; ++m) {
-            for (int e = t; e < nx * nu; e += THREADS) {
-                const int x = e / nu, u = e % nu;
-                double s = 0.0;
-                for (int y = 0; y < nx; ++y) s = __builtin_fma(Xf[x * nx + y], M[((m - 1) * nx + y) * nu + u], s);
-                M[(m * nx + x) * nu + u] = s;
-            }
+        PROF_START;
+        ldsd *Ma = lds + o.Linv, *X = lds + o.X, *Xf = lds + o.Xf, *Lam = lds + o.Lam;
+        ldsd *Am = lds + o.AB, *Bm = Am + nx * nx;
+        {   // stage the shared block, the plant and the model
+            ldsd *S = lds + o.SH;
+            for (int e = t; e < o.shn; e += THREADS) S[e] = p.sh[e];
+            const long long rs = (long long)nx * nx + nx * nu + nx;
+            for (int e = t; e < nx * nx; e += THREADS) Am[e] = p.rec ? p.rec[b * rs + e] : p.A[(long long)e * Bsz + b];
+            for (int e = t; e < nx * nu; e += THREADS) Bm[e] = p.rec ? p.rec[b * rs + nx * nx + e] : p.B[(long long)e * Bsz + b];
+            for (int e = t; e < nb * BLK; e += THREADS) { Ma[e] = 0.0; X[e] = 0.0; }
             __syncthreads();
-        }
-        for (int k = 1; k < N; ++k) {                             // Xf[k] = A^(k+1)
-            for (int e = t; e < nx * nx; e += THREADS) {
-                const int x = e / nx, y = e % nx;
-                double s = 0.0;
-                for (int z = 0; z < nx; ++z) s = __builtin_fma(Xf[x * nx + z], Xf[((k - 1) * nx + z) * nx + y], s);
-                Xf[(k * nx + x) * nx + y] = s;
+            if (p.true_per_instance) {
+                for (int e = t; e < nx * nx; e += THREADS) S[p.so.At + e] = p.At[(long long)e * Bsz + b];
+                for (int e = t; e < nx * nu; e += THREADS) S[p.so.Bt + e] = p.Bt[(long long)e * Bsz + b];
             }
-            __syncthreads();
         }
-        // PM[m] = P_T M[m],  DM[m] = (Q - P_T) M[m]
-        for (int e = t; e < N * nx * nu; e += THREADS) {
-            const int m = e / (nx * nu), x = (e / nu) % nx, u = e % nu;
-            double s1 = 0.0, s2 = 0.0;
-            for (int y = 0; y < nx; ++y) {
-                const double mv = M[(m * nx + y) * nu + u];
-                s1 = __builtin_fma(sh[p.so.P + x * nx + y], mv, s1);
-                s2 = __builtin_fma(sh[p.so.Q + x * nx + y] - sh[p.so.P + x * nx + y], mv, s2);
+        const ldsd *sh = shd();
+        // [M_m | A^(m+1)] = A [M_(m-1) | A^m]: one thread per entry of the nx x (nu + nx) matrix (two for the
+        // widest shapes: nx (nu + nx) <= 16 * 24)
+        {
+            const int wdt = nu + nx, cnt = nx * wdt;
+            auto ma_row = [&](int m, int u) { const int i = (N - 1 - m) * nu + u; return Ma + (i / BS) * BLK + (i % BS) * LD; };
+            auto entry = [&](int e, int m) {
+                const int x = e / wdt, c = e - x * wdt;
+                if (m == 0) {
+                    if (c < nu) ma_row(0, c)[x] = Bm[x * nu + c];
+                    else Xf[x * nx + (c - nu)] = Am[x * nx + (c - nu)];
+                } else if (c < nu) ma_row(m, c)[x] = ldot(Am + x * nx, 1, ma_row(m - 1, c), 1, nx);
+                else Xf[m * nx * nx + x * nx + (c - nu)] = ldot(Am + x * nx, 1, Xf + (m - 1) * nx * nx + (c - nu), nx, nx);   // Xf[m] = A^(m+1)
+            };
+            for (int m = 0; m < N; ++m) {
+                if (t < cnt) entry(t, m);
+                if (t + THREADS < cnt) entry(t + THREADS, m);
+                __syncthreads();
             }
-            PM[e] = s1; DM[e] = s2;
         }
-        // zero the image of K, unit diagonal on the padding rows
-        const int cnt = nb * (nb + 1) / 2 * BLK;
-        for (int e = t; e < cnt; e += THREADS) lds[o.K + e] = 0.0;
+        PROF(0);
+        const int wave = t >> 6;
+        // Cq = Ma (Q Ma)' into the lower blocks of K
+        weight_rows(Ma, sh + p.so.Q, X);
         __syncthreads();
-        if (t >= n && t < np) *kaddr(t, t) = 1.0;
-        // H by diagonals: with a, b = stages to go of the row / column block, b = a + d,
-        //   S(a, b) = S(a-1, b-1) + M_a' P_T M_b + M_{a-1}' (Q - P_T) M_{b-1},   S(0, b) = M_0' P_T M_b,
-        // block row bi = N-1-a, block column bj = N-1-b <= bi.  One chain per (d, ui, uj).
-        for (int ch = t; ch < N * nu * nu; ch += THREADS) {
-            const int d = ch / (nu * nu), ui = (ch / nu) % nu, uj = ch % nu;
-            double S = 0.0;
-            for (int a = 0; a + d < N; ++a) {
-                const int bq = a + d;
-                double s = S;
-                for (int x = 0; x < nx; ++x) s = __builtin_fma(M[(a * nx + x) * nu + ui], PM[(bq * nx + x) * nu + uj], s);
-                if (a > 0)
-                    for (int x = 0; x < nx; ++x) s = __builtin_fma(M[((a - 1) * nx + x) * nu + ui], DM[((bq - 1) * nx + x) * nu + uj], s);
-                S = s;
-                const int i = (N - 1 - a) * nu + ui, j = (N - 1 - bq) * nu + uj;
-                double val = S + ((d == 0) ? sh[p.so.R + ui * nu + uj] : 0.0);
-                val *= 2.0;
-                if (i / BS > j / BS || (i / BS == j / BS)) {
-                    if (j <= i || i / BS == j / BS) {
-                        if (j / BS <= i / BS) *kaddr(i, j) = val;
-                    }
+        {
+            int cnt = 0;
+            for (int ib = 0; ib < nb; ++ib)
+                for (int jb = 0; jb <= ib; ++jb, ++cnt) {
+                    if ((cnt & 3) != wave) continue;
+                    d4_t c = {0.0, 0.0, 0.0, 0.0};
+                    c = block_xyt(Ma + ib * BLK, X + jb * BLK, c, false);
+                    tile_store(lds + o.K + blk_index(ib, jb) * BLK, c);
                 }
-                if (i != j && i / BS == j / BS) *kaddr(j, i) = val;           // both triangles inside a diagonal block
-            }
         }
         __syncthreads();
+        PROF(1);
+        // suffix sums along the stage diagonals, in place; R on the stage-diagonal blocks
+        for (int ch = t; ch < n * nu; ch += THREADS) {
+            const int i0 = ch / nu, j0 = ch - i0 * nu;
+            if (i0 < j0) continue;                                   // upper triangle of a stage block: mirrored below
+            const double radd = (i0 < nu) ? sh[p.so.R + i0 * nu + j0] : 0.0;
+            double run = 0.0;
+            int s = (n - 1 - i0) / nu;
+            for (; s >= 7; s -= 8) {                                 // eight loads in flight, then eight stores
+                ldsd *e[8];
+                double tmp[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { e[k] = kaddr(i0 + (s - k) * nu, j0 + (s - k) * nu); tmp[k] = *e[k]; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { *e[k] = run + radd; run += tmp[k]; }
+            }
+            for (; s >= 0; --s) {
+                ldsd *e = kaddr(i0 + s * nu, j0 + s * nu);
+                const double tmp = *e;
+                *e = run + radd;
+                run += tmp;
+            }
+        }
+        weight_rows(Ma, sh + p.so.P, X);                             // X is not read by the pass above
+        __syncthreads();
+        {   // K <- 2 (K + Ma (P_T Ma)')
+            int cnt = 0;
+            for (int ib = 0; ib < nb; ++ib)
+                for (int jb = 0; jb <= ib; ++jb, ++cnt) {
+                    if ((cnt & 3) != wave) continue;
+                    ldsd *C = lds + o.K + blk_index(ib, jb) * BLK;
+                    d4_t c = tile_load(C);
+                    c = block_xyt(Ma + ib * BLK, X + jb * BLK, c, false);
+                    c *= 2.0;
+                    tile_store(C, c);
+                }
+        }
+        __syncthreads();
+        {   // diagonal blocks: upper triangle from the lower one; unit diagonal on the padding rows
+            const int r = t / BS, c = t % BS;
+            for (int kb = 0; kb < nb; ++kb) {
+                ldsd *D = lds + o.K + blk_index(kb, kb) * BLK;
+                if (r < c) D[r * LD + c] = D[c * LD + r];
+            }
+            __syncthreads();
+            if (t >= n && t < np) *kaddr(t, t) = 1.0;
+            for (int e = t; e < nb * BLK; e += THREADS) X[e] = 0.0;  // becomes the block-row image of [Fq | qr]
+        }
+        __syncthreads();
+        PROF(2);
         const int total = nb * (nb + 1) / 2 * BLK;
 #pragma unroll
         for (int m = 0; m < PREG; ++m) {
@@ -251,99 +374,187 @@ struct Wg {
         }
         // Fq = 2 Gamma' Qbar Phi by the costate recursion on matrices:
         //   Lam_N = P_T A^N,  Lam_k = Q A^k + A' Lam_{k+1},  Fq block row bi = 2 B' Lam_{bi+1}
-        double *G = lds + o.G;
-        for (int e = t; e < np * nx; e += THREADS) G[e] = 0.0;
-        int cur = 0;
-        for (int k = N; k >= 1; --k) {
-            const double *Ak = Xf + (k - 1) * nx * nx;            // A^k
-            const double *W = sh + ((k == N) ? p.so.P : p.so.Q);
-            __syncthreads();
-            for (int e = t; e < nx * nx; e += THREADS) {
-                const int x = e / nx, y = e % nx;
-                double s = 0.0;
-                for (int z = 0; z < nx; ++z) s = __builtin_fma(W[x * nx + z], Ak[z * nx + y], s);
-                if (k < N)
-                    for (int z = 0; z < nx; ++z) s = __builtin_fma(Xf[z * nx + x], Lam[cur * nx * nx + z * nx + y], s);   // A'[x][z] = A[z][x]
-                Lam[(cur ^ 1) * nx * nx + e] = s;
-            }
-            cur ^= 1;
-            __syncthreads();
-            const int bi = k - 1;
-            for (int e = t; e < nu * nx; e += THREADS) {
-                const int ui = e / nx, a = e % nx;
-                double s = 0.0;
-                for (int x = 0; x < nx; ++x) s = __builtin_fma(M[x * nu + ui], Lam[cur * nx * nx + x * nx + a], s);        // B = M[0]
-                G[(bi * nu + ui) * nx + a] = 2.0 * s;
+        // (rows of Fq are written one step behind the recursion by a second group of threads)
+        {
+            const bool mine = t < nx * nx;
+            const int x = mine ? t / nx : 0, y = mine ? t % nx : 0;
+            const int t2 = t - 64;
+            const bool mine2 = t2 >= 0 && t2 < nu * nx;
+            const int ui = mine2 ? t2 / nx : 0, a = mine2 ? t2 % nx : 0;
+            int cur = 0;
+            for (int k = N; k >= 0; --k) {
+                if (mine && k >= 1) {
+                    const ldsd *Ak = Xf + (k - 1) * nx * nx;       // A^k
+                    const ldsd *Wt = sh + ((k == N) ? p.so.P : p.so.Q);
+                    double s = ldot(Wt + x * nx, 1, Ak + y, nx, nx);
+                    if (k < N) s = ldot(Am + x, nx, Lam + cur * nx * nx + y, nx, nx, s);
+                    Lam[(cur ^ 1) * nx * nx + t] = s;
+                }
+                if (mine2 && k < N) {                                // Lam[cur] = Lam_{k+1}: row block bi = k
+                    const double s = ldot(Bm + ui, nu, Lam + cur * nx * nx + a, nx, nx);
+                    const int i = k * nu + ui;
+                    X[(i / BS) * BLK + (i % BS) * LD + a] = 2.0 * s;
+                }
+                cur ^= 1;
+                __syncthreads();
             }
         }
-        __syncthreads();
-        // presolve data: G <- -P^-1 Fq, one column at a time through the factor of P
-        load_K(false, 0.0);
-        factor();
-        for (int a = 0; a < nx; ++a) {
-            if (t < np) lds[o.vb + t] = own ? G[t * nx + a] : 0.0;
-            __syncthreads();
-            solve_vb();
-            if (own) G[t * nx + a] = -lds[o.vb + t];
-            __syncthreads();
-        }
+        PROF(3);
         // constant part of the linear term: qr = 2 gref + P centre, with
         //   d_r = -xref_r,  lam_r = Q_r d_r + A' lam_{r+1},  gref_r = B' lam_r - R uref_r   (columns r = 0..N-1 <-> x_{r+1}, u_r)
-        double *gq = lds + o.vw;
+        ldsd *gq = lds + o.vw;
         if (t < np) gq[t] = 0.0;
         if (p.has_ref) {
-            const double *xr = sh + p.so.xref, *ur = sh + p.so.uref;
-            double *lam = Lam, *lam2 = Lam + nx;
+            const ldsd *xr = sh + p.so.xref, *ur = sh + p.so.uref;
+            ldsd *lam = Lam, *lam2 = Lam + nx;
             if (t < nx) lam[t] = 0.0;
             for (int r = N - 1; r >= 0; --r) {
-                const double *Qr = sh + ((r < N - 1) ? p.so.Q : p.so.P);
+                const ldsd *Qr = sh + ((r < N - 1) ? p.so.Q : p.so.P);
                 __syncthreads();
                 if (t < nx) {
                     double a = 0.0;
                     for (int y = 0; y < nx; ++y) a = __builtin_fma(Qr[t * nx + y], -xr[y * N + r], a);
-                    for (int y = 0; y < nx; ++y) a = __builtin_fma(Xf[y * nx + t], lam[y], a);
+                    for (int y = 0; y < nx; ++y) a = __builtin_fma(Am[y * nx + t], lam[y], a);
                     lam2[t] = a;
                 }
                 __syncthreads();
                 if (t < nx) lam[t] = lam2[t];
                 if (t < nu) {
                     double a = 0.0;
-                    for (int x = 0; x < nx; ++x) a = __builtin_fma(M[x * nu + t], lam2[x], a);
+                    for (int x = 0; x < nx; ++x) a = __builtin_fma(Bm[x * nu + t], lam2[x], a);
                     for (int j = 0; j < nu; ++j) a = __builtin_fma(-sh[p.so.R + t * nu + j], ur[j * N + r], a);
                     gq[r * nu + t] = 2.0 * a;
                 }
             }
             __syncthreads();
         }
-        const double gref2 = (t < np) ? gq[t] : 0.0;
-        __syncthreads();
-        if (t < np) gq[t] = own ? ctr : 0.0;
-        load_K(false, 0.0);
-        const double qr = gref2 + symv_row(gq);
-        vr = 0.0;
-        if (block_any(own && qr != 0.0)) {
+        double qr = (t < np) ? gq[t] : 0.0;
+        if (block_any(own && ctr != 0.0)) {
+            if (t < np) gq[t] = own ? ctr : 0.0;
             __syncthreads();
-            if (t < np) lds[o.vb + t] = own ? qr : 0.0;
-            factor();
-            solve_vb();
-            vr = own ? -lds[o.vb + t] : 0.0;
+            qr += symv_row(gq);                                      // K still holds P here
+        }
+        const bool have_qr = block_any(own && qr != 0.0);
+        const bool qr_rides = have_qr && nx < BS;                    // as column nx of the block-row image of Fq
+        if (qr_rides && t < np) X[(t / BS) * BLK + (t % BS) * LD + nx] = own ? qr : 0.0;
+        PROF(4);
+        // W = P^-1 in place of P;  [G | v_r] <- -W [Fq | qr] as block products
+        make_W(false);
+        PROF(5);
+        vr = 0.0;
+        {
+            ldsd *G = lds + o.G;
+            const int lane = t & 63, col = lane & 15, r0 = lane >> 4;
+            for (int ib = wave; ib < nb; ib += 4) {
+                d4_t c = {0.0, 0.0, 0.0, 0.0};
+                for (int jb = 0; jb < nb; ++jb)
+                    c = (jb <= ib) ? block_mm<false, true>(lds + o.K + blk_index(ib, jb) * BLK, X + jb * BLK, c, true)
+                                   : block_mm<true, true>(lds + o.K + blk_index(jb, ib) * BLK, X + jb * BLK, c, true);
+                const double cv[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = ib * BS + r0 + 4 * r;
+                    if (col < nx) G[col * np + i] = cv[r];
+                    else if (col == nx) lds[o.vb + i] = cv[r];
+                }
+            }
+            __syncthreads();
+            if (qr_rides) vr = own ? lds[o.vb + t] : 0.0;
+            else if (have_qr) {
+                if (t < np) gq[t] = own ? qr : 0.0;
+                __syncthreads();
+                vr = own ? -symv_row(gq) : 0.0;
+            }
             __syncthreads();
         }
+        PROF(6);
     }
 
-    // v_unc = G x for my row (x in LDS at o.xs)
+    // v_unc = G x + v_r for my row (x in LDS at o.xs)
     __device__ __forceinline__ double vunc() const
     {
-        double s = own ? vr : 0.0;
-        if (own) for (int a = 0; a < nx; ++a) s = __builtin_fma(lds[o.G + t * nx + a], lds[o.xs + a], s);
-        return s;
+        return own ? ldot(lds + o.G + t, np, lds + o.xs, 1, nx, vr) : 0.0;
     }
 
-    // ---- primal-dual active-set iterations from the face in `act` (my row: -1 / 0 / +1) ----
-    __device__ bool pdas(double &act, double scale, int maxit, int &nfact, double &vout)
+    // rank of my row among the rows with flag a (thread order), and their number m
+    __device__ __forceinline__ int rank_active(bool a, int &m)
+    {
+        const unsigned long long bal = __ballot(a);
+        const int lane = t & 63, wave = t >> 6;
+        ldsi *wc = (ldsi *)(lds + o.red + 12);
+        if (lane == 0) wc[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0;
+        m = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int c = wc[w]; off += (w < wave) ? c : 0; m += c; }
+        __syncthreads();
+        return off + __popcll(bal & ((1ull << lane) - 1ull));
+    }
+
+    // ---- active-set iterations from the dual side (see the header): 0 converged, 1 hand over to the fallback ----
+    __device__ __forceinline__ int pdas_dual(double vu, double &act, int maxit, int &nfact, double &vout)
+    {
+        ldsd *S = lds + o.S, *T = lds + o.T, *rb = lds + o.vb, *lamv = lds + o.lam, *red = lds + o.red;
+        ldsi *list = (ldsi *)(lds + o.list);
+        for (int it = 0; it < maxit; ++it) {
+            int m;
+            const bool a = own && act != 0.0;
+            const int rk = rank_active(a, m);
+            if (m > o.smax * BS) return 1;
+            double vi = vu, lmine = 0.0;
+            if (m > 0) {
+                const int nbm = (m + BS - 1) / BS, mp = nbm * BS;
+                if (a) { list[rk] = t; rb[rk] = vu - act * h; }
+                if (t >= m && t < mp) rb[t] = 0.0;
+                __syncthreads();
+                const int cnt = nbm * (nbm + 1) / 2 * BLK;
+                for (int e = t; e < cnt; e += THREADS) {          // S = W_AA, identity outside
+                    const int bidx = e / BLK, w = e - bidx * BLK, r = w / LD, c = w - r * LD;
+                    int ab = 0;
+                    while ((ab + 1) * (ab + 2) / 2 <= bidx) ++ab;
+                    const int bb = bidx - ab * (ab + 1) / 2, ia = ab * BS + r, ib = bb * BS + c;
+                    double val = (ia == ib) ? 1.0 : 0.0;
+                    if (c < BS && ia < m && ib < m) val = wsym(list[ia], list[ib]);
+                    S[e] = val;
+                }
+                __syncthreads();
+                const ldsd *sol;
+                bool ok = true;
+                if (nbm == 1) {
+                    if (t < 64) ok = small_spd_solve(S, T, rb, lamv, m);
+                    ok = __syncthreads_and(ok ? 1 : 0) != 0;
+                    sol = lamv;
+                } else {
+                    ok = chol_blocked(S, lds + o.Linv, nbm, flag());
+                    solve_blocked(S, lds + o.Linv, nbm, rb);
+                    sol = rb;
+                }
+                if (!ok) return 1;
+                nfact += 1;
+                if (own) for (int k = 0; k < m; ++k) vi = __builtin_fma(-wsym(t, list[k]), sol[k], vi);
+                if (a) { lmine = sol[rk]; vi = act * h; }
+            }
+            const double gtol = 1e-10 * block_max(a ? fabs(lmine) : 0.0, red);
+            double na = act;
+            if (own) {
+                if (!a) na = (vi < -h * (1.0 + 1e-12)) ? -1.0 : ((vi > h * (1.0 + 1e-12)) ? 1.0 : 0.0);
+                else na = (act < 0.0) ? ((lmine <= gtol) ? -1.0 : 0.0) : ((lmine >= -gtol) ? 1.0 : 0.0);
+            }
+            const bool anybad = block_any(own && !(fabs(vi) < 1e300));
+            const bool anych = block_any(own && na != act);
+            if (anybad) return 1;
+            act = na;
+            if (!anych) { vout = vi; return 0; }
+        }
+        return 1;
+    }
+
+    // ---- primal-dual active-set iterations on the n x n system, from the face in `act` (fallback path) ----
+    __device__ __forceinline__ bool pdas(double &act, double scale, int maxit, int &nfact, double &vout)
     {
         const double gtol = 1e-10 * scale;
-        double *vb = lds + o.vb, *vw = lds + o.vw, *actv = lds + o.act;
+        ldsd *vb = lds + o.vb, *vw = lds + o.vw, *actv = lds + o.act;
         for (int k = 0; k < maxit; ++k) {
             if (t < np) { actv[t] = own ? act : 0.0; vw[t] = own ? act * h : 0.0; }
             load_K(false, 0.0);                                   // K = P (barrier inside publishes act / vw)
@@ -374,10 +585,10 @@ struct Wg {
         return false;
     }
 
-    // ---- Mehrotra predictor-corrector from the current iterate until gap / residual <= eps_rel ----
-    __device__ int ipm_run(double scale, double hmin, double eps_rel, int &budget, int &iters)
+    // ---- Mehrotra predictor-corrector from the current iterate until gap / residual <= eps_rel (fallback path) ----
+    __device__ __forceinline__ int ipm_run(double scale, double hmin, double eps_rel, int &budget, int &iters)
     {
-        double *vb = lds + o.vb, *red = lds + o.red;
+        ldsd *vb = lds + o.vb, *red = lds + o.red;
         const double inv2n = 1.0 / (2.0 * n), mu_tol = eps_rel * scale * hmin, rd_tol = eps_rel * scale;
         for (; budget > 0; --budget) {
             const double mu = block_sum(own ? sl * zl + su * zu : 0.0, red) * inv2n;
@@ -415,20 +626,13 @@ struct Wg {
     }
 
     // ---- one box QP at the state in LDS (o.xs); result in v (my row) ----
-    __device__ int solve_qp(int &iters)
+    __device__ __forceinline__ int solve_qp(int &iters)
     {
-        double *red = lds + o.red;
+        ldsd *red = lds + o.red;
         const double vu = vunc();
         v = vu;
         if (!block_any(own && !(fabs(vu) <= h))) { act_prev = 0.0; return 0; }     // presolve: interior minimiser
-        // q = -P v_unc
-        if (t < np) lds[o.vw + t] = own ? vu : 0.0;
-        load_K(false, 0.0);
-        qs = -symv_row(lds + o.vw);
-        __syncthreads();
-        double scale = block_max(own ? fabs(qs) : 0.0, red);
-        if (!(scale < 1e300)) { v = 0.0; act_prev = 0.0; return 2; }
-        scale = fmax(scale, 1e-100);
+        if (block_any(own && !(fabs(vu) < 1e300))) { v = 0.0; act_prev = 0.0; return 2; }
         // warm start: the previous step's face shifted by one stage, else the rows where v_unc leaves the box
         double act;
         const bool have_prev = block_any(own && act_prev != 0.0);
@@ -440,32 +644,39 @@ struct Wg {
         } else {
             act = own ? ((vu < -h) ? -1.0 : ((vu > h) ? 1.0 : 0.0)) : 0.0;
         }
-        int status = 0;
         double vsol = 0.0;
-        bool done = false;
-        if (p.warm_start) done = pdas(act, scale, 8, iters, vsol);
-        if (!done) {
-            // fallback: interior point in stages, active-set finishing after each stage
-            const double hmin = -block_max(own ? -h : -1e300, red);
-            const double z0 = p.z0_scale * scale;
-            sl = h; su = h; zl = z0; zu = z0; rd = qs;
-            int budget = p.max_iter;
-            double e_prev = 1e300;
-            status = 1;
-            for (int stage = 0; stage < 3 && !done; ++stage) {
-                const double e = !p.polish ? p.eps : (stage == 0 ? fmax(1e-6, p.eps) : (stage == 1 ? fmax(1e-9, p.eps) : p.eps));
-                if (!(e < e_prev)) continue;
-                e_prev = e;
-                status = ipm_run(scale, hmin, e, budget, iters);
-                if (status == 2) { vsol = 0.0; break; }
-                vsol = sl - h;
-                if (!p.polish) break;
-                act = own ? ((zl > sl) ? -1.0 : ((zu > su) ? 1.0 : 0.0)) : 0.0;
-                double vp;
-                if (pdas(act, scale, 4, iters, vp)) { vsol = vp; status = 0; done = true; }
-                if (budget <= 0) break;
-            }
+        if (p.warm_start && pdas_dual(vu, act, 10, iters, vsol) == 0) {
+            v = vsol;
+            act_prev = act;
+            return 0;
         }
+        // fallback: interior point in stages with primal active-set finishing, on n x n matrices in the W region
+        if (t < np) lds[o.vw + t] = own ? vu : 0.0;
+        load_K(false, 0.0);
+        qs = -symv_row(lds + o.vw);                               // q = -P v_unc
+        __syncthreads();
+        double scale = block_max(own ? fabs(qs) : 0.0, red);
+        scale = fmax(scale, 1e-100);
+        const double hmin = -block_max(own ? -h : -1e300, red);
+        const double z0 = p.z0_scale * scale;
+        sl = h; su = h; zl = z0; zu = z0; rd = qs;
+        int budget = p.max_iter, status = 1;
+        double e_prev = 1e300;
+        bool done = false;
+        for (int stage = 0; stage < 3 && !done; ++stage) {
+            const double e = !p.polish ? p.eps : (stage == 0 ? fmax(1e-6, p.eps) : (stage == 1 ? fmax(1e-9, p.eps) : p.eps));
+            if (!(e < e_prev)) continue;
+            e_prev = e;
+            status = ipm_run(scale, hmin, e, budget, iters);
+            if (status == 2) { vsol = 0.0; break; }
+            vsol = sl - h;
+            if (!p.polish) break;
+            act = own ? ((zl > sl) ? -1.0 : ((zu > su) ? 1.0 : 0.0)) : 0.0;
+            double vp;
+            if (pdas(act, scale, 4, iters, vp)) { vsol = vp; status = 0; done = true; }
+            if (budget <= 0) break;
+        }
+        make_W(true);
         v = vsol;
         act_prev = (status == 2) ? 0.0 : act;
         return status;
@@ -474,7 +685,8 @@ struct Wg {
 
 __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
 {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_raw[];
+    ldsd *lds = (ldsd *)lds_raw;
     const int t = threadIdx.x;
     const long long slot = blockIdx.x;
     const long long b = p.perm ? (long long)p.perm[slot] : slot;
@@ -487,8 +699,8 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
     w.vr = 0.0;
     w.act_prev = 0.0; w.v = 0.0; w.qs = 0.0; w.sl = w.su = w.zl = w.zu = 1.0; w.rd = 0.0;
     w.setup(b);
-    const double *sh = p.sh;
-    double *xs = lds + w.o.xs;
+    const ldsd *sh = w.shd();
+    ldsd *xs = lds + w.o.xs;
     auto load_x0 = [&]() {
         if (t < nx) xs[t] = p.rec ? p.rec[b * (nx * nx + nx * nu + nx) + nx * nx + nx * nu + t] : p.x0[(long long)t * Bsz + b];
         __syncthreads();
@@ -500,81 +712,95 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
         __syncthreads();
     };
     int iters = 0, status = 0;
-    // V_N by rolling the model forward with the optimal inputs (thread 0; tiny)
-    auto value_fn = [&](const double *x0v) -> double {
-        double cost = 0.0;
-        if (t == 0) {
-            double xsv[16], xn[16];
-            for (int i = 0; i < nx; ++i) xsv[i] = x0v[i];
-            for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) cost = __builtin_fma(xsv[i] * sh[p.so.Q + i * nx + j], xsv[j], cost);
-            const double *A = lds + w.o.Xf, *Bm = lds + w.o.M;
-            for (int s = 0; s < N; ++s) {
-                for (int i = 0; i < nx; ++i) {
-                    double acc = 0.0;
-                    for (int j = 0; j < nx; ++j) acc = __builtin_fma(A[i * nx + j], xsv[j], acc);
-                    for (int k = 0; k < nu; ++k) acc = __builtin_fma(Bm[i * nu + k], lds[w.o.vw + s * nu + k], acc);
-                    xn[i] = acc;
-                }
-                const int oQ = (s < N - 1) ? p.so.Q : p.so.P;
-                for (int i = 0; i < nx; ++i) xsv[i] = xn[i];
-                if (p.has_ref) for (int i = 0; i < nx; ++i) xn[i] -= sh[p.so.xref + i * N + s];
-                for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) cost = __builtin_fma(xn[i] * sh[oQ + i * nx + j], xn[j], cost);
-                for (int k = 0; k < nu; ++k) for (int j = 0; j < nu; ++j) {
-                    const double dk = lds[w.o.vw + s * nu + k] - (p.has_ref ? sh[p.so.uref + k * N + s] : 0.0);
-                    const double dj = lds[w.o.vw + s * nu + j] - (p.has_ref ? sh[p.so.uref + j * N + s] : 0.0);
-                    cost = __builtin_fma(dk * sh[p.so.R + k * nu + j], dj, cost);
-                }
+    // V_N by rolling the model forward with the optimal inputs (in LDS at vw): states by the first nx threads,
+    // then one stage cost per thread and a workgroup sum.  Every thread gets the value.
+    auto value_fn = [&](const ldsd *x0v) -> double {
+        ldsd *Xs = lds + w.o.Xs;
+        const ldsd *A = lds + w.o.AB, *Bm = A + nx * nx, *uu = lds + w.o.vw;
+        if (t < nx) Xs[t] = x0v[t];
+        __syncthreads();
+        for (int s = 0; s < N; ++s) {
+            if (t < nx) {
+                Xs[(s + 1) * nx + t] = ldot(Bm + t * nu, 1, uu + s * nu, 1, nu, ldot(A + t * nx, 1, Xs + s * nx, 1, nx));
             }
-        }
-        return cost;
-    };
-    if (p.mode == MODE_SOLVE) {
-        load_x0();
-        status = w.solve_qp(iters);
-        publish_v();
-        const double vn = value_fn(xs);
-        if (t == 0) p.VN[b] = vn;
-        if (t < nu) p.u0[(long long)t * Bsz + b] = lds[w.o.vw + t];
-    } else if (p.mode == MODE_MAXVN) {
-        double best = -1e308;
-        for (int k = 0; k < p.K; ++k) {
             __syncthreads();
-            if (t < nx) xs[t] = sh[p.so.x0s + t * p.K + k];
+        }
+        double c = 0.0;
+        if (t <= N) {
+            const int st = t;
+            const ldsd *Qs = sh + ((st == N) ? p.so.P : p.so.Q);
+            const bool rf = p.has_ref && st >= 1;
+            for (int i = 0; i < nx; ++i) {
+                const double di = Xs[st * nx + i] - (rf ? sh[p.so.xref + i * N + st - 1] : 0.0);
+                double r = 0.0;
+                for (int j = 0; j < nx; ++j) r = __builtin_fma(Qs[i * nx + j], Xs[st * nx + j] - (rf ? sh[p.so.xref + j * N + st - 1] : 0.0), r);
+                c = __builtin_fma(di, r, c);
+            }
+            if (st < N)
+                for (int k = 0; k < nu; ++k) {
+                    const double dk = uu[st * nu + k] - (p.has_ref ? sh[p.so.uref + k * N + st] : 0.0);
+                    double r = 0.0;
+                    for (int j = 0; j < nu; ++j) r = __builtin_fma(sh[p.so.R + k * nu + j], uu[st * nu + j] - (p.has_ref ? sh[p.so.uref + j * N + st] : 0.0), r);
+                    c = __builtin_fma(dk, r, c);
+                }
+        }
+        return block_sum(c, lds + w.o.red);
+    };
+    PROF_START;
+    // one loop for the three entry points: a single QP (solve), K start states (max V_N), T closed-loop steps
+    // (utils_class.py:266-283; thread i < nx carries x_i (Q x)_i of J_T, thread k < nu carries u_k (R u)_k)
+    const int mode = p.mode;
+    const int nsteps = (mode == MODE_SOLVE) ? 1 : ((mode == MODE_MAXVN) ? p.K : p.T);
+    const ldsd *uu = lds + w.o.vw;
+    double cost = 0.0, best = -1e308;
+    auto stage_cost = [&](bool with_u) {
+        if (t < nx) {
+            cost = __builtin_fma(xs[t], ldot(sh + p.so.Q + t * nx, 1, xs, 1, nx), cost);
+        }
+        if (with_u && t < nu) {
+            cost = __builtin_fma(uu[t], ldot(sh + p.so.R + t * nu, 1, uu, 1, nu), cost);
+        }
+    };
+    if (mode != MODE_MAXVN) load_x0();
+    if (mode == MODE_ROLLOUT) {
+        stage_cost(false);
+        if (p.X && t < nx) p.X[((long long)t * (p.T + 1)) * Bsz + b] = xs[t];
+    }
+    for (int step = 0; step < nsteps; ++step) {
+        if (mode == MODE_MAXVN) {
+            __syncthreads();
+            if (t < nx) xs[t] = p.sh[p.so.x0s + t * p.K + step];
             __syncthreads();
             w.act_prev = 0.0;
-            const int st = w.solve_qp(iters);
-            status = st > status ? st : status;
-            publish_v();
-            const double vn = value_fn(xs);
-            best = (vn > best || vn != vn) ? vn : best;
         }
-        if (t == 0) p.MV[b] = best;
-    } else {
-        load_x0();
-        double cost = 0.0;
-        if (t == 0) for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) cost = __builtin_fma(xs[i] * sh[p.so.Q + i * nx + j], xs[j], cost);
-        if (p.X && t < nx) p.X[((long long)t * (p.T + 1)) * Bsz + b] = xs[t];
-        for (int step = 0; step < p.T; ++step) {
-            const int st = w.solve_qp(iters);
-            status = st > status ? st : status;
-            publish_v();
+        const int st = w.solve_qp(iters);
+        status = st > status ? st : status;
+        publish_v();
+        if (mode == MODE_ROLLOUT) {
             double xn = 0.0;
-            if (t < nx) {
-                for (int j = 0; j < nx; ++j) xn = __builtin_fma(p.true_per_instance ? p.At[(long long)(t * nx + j) * Bsz + b] : sh[p.so.At + t * nx + j], xs[j], xn);
-                for (int k = 0; k < nu; ++k) xn = __builtin_fma(p.true_per_instance ? p.Bt[(long long)(t * nu + k) * Bsz + b] : sh[p.so.Bt + t * nu + k], lds[w.o.vw + k], xn);
-            }
+            if (t < nx) xn = ldot(sh + p.so.Bt + t * nu, 1, uu, 1, nu, ldot(sh + p.so.At + t * nx, 1, xs, 1, nx));
             __syncthreads();
             if (t < nx) xs[t] = xn;
             __syncthreads();
-            if (t == 0) {
-                for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) cost = __builtin_fma(xs[i] * sh[p.so.Q + i * nx + j], xs[j], cost);
-                for (int k = 0; k < nu; ++k) for (int j = 0; j < nu; ++j) cost = __builtin_fma(lds[w.o.vw + k] * sh[p.so.R + k * nu + j], lds[w.o.vw + j], cost);
-            }
+            stage_cost(true);
             if (p.X && t < nx) p.X[((long long)t * (p.T + 1) + step + 1) * Bsz + b] = xs[t];
-            if (p.U && t < nu) p.U[((long long)t * p.T + step) * Bsz + b] = lds[w.o.vw + t];
+            if (p.U && t < nu) p.U[((long long)t * p.T + step) * Bsz + b] = uu[t];
+        } else {
+            const double vn = value_fn(xs);
+            best = (vn > best || vn != vn) ? vn : best;
+            if (mode == MODE_SOLVE) {
+                if (t == 0) p.VN[b] = vn;
+                if (t < nu) p.u0[(long long)t * Bsz + b] = uu[t];
+            }
         }
-        if (t == 0) p.JT[b] = cost;
     }
+    if (mode == MODE_ROLLOUT) {
+        cost = block_sum(cost, lds + w.o.red);
+        if (t == 0) p.JT[b] = cost;
+    } else if (mode == MODE_MAXVN) {
+        if (t == 0) p.MV[b] = best;
+    }
+    PROF(13);
     if (t == 0) {
         if (p.status) p.status[b] = status;
         if (p.iters) p.iters[b] = iters;
@@ -593,7 +819,17 @@ bool launch_wg(const KParams &p, hipStream_t stream, const char **name)
         }
         attr_bytes = bytes;
     }
+#ifdef LQMPC_WG_PROF
+    long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_prof), z, sizeof z);
+#endif
     hipLaunchKernelGGL(lqmpc_wg_kernel, dim3((unsigned)p.Bsz), dim3(256), bytes, stream, p);
+#ifdef LQMPC_WG_PROF
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_wg_prof), sizeof z);
+    fprintf(stderr, "wg prof (block 0 ticks): chains %lld Cq %lld H %lld Fq %lld qr %lld makeW %lld [chol %lld triinv %lld ztz %lld] G/vr %lld | solve_qp %lld value_fn %lld rollout %lld\n",
+            z[0], z[1], z[2], z[3], z[4], z[5], z[8], z[9], z[10], z[6], z[11], z[12], z[13]);
+#endif
     if (name) *name = "lqmpc_wg_kernel";
     return true;
 }
