@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -17,6 +18,7 @@ void launch_generic(const KParams &p, hipStream_t stream);
 // lqmpc_spec.hip: returns false when no specialisation is built for (nx,nu,N)
 bool spec_available(int nx, int nu, int N);
 bool launch_spec(const KParams &p, hipStream_t stream, const char **name);
+bool spec_tiered_available(int nx, int nu, int N);
 // lqmpc_wg.hip: one instance per workgroup, 32 < n <= 128
 bool wg_supported(const KParams &p, const double *lb, const double *ub);
 bool launch_wg(const KParams &p, hipStream_t stream, const char **name);
@@ -376,6 +378,12 @@ int lqmpc_rollout_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
     if (order) {
         rc = build_order(h, p);
         if (rc) return rc;
+        // the hardest instances (first in the order) on a wavefront each: see lqmpc_spec_tiered_kernel
+        if (lqmpc::spec_tiered_available(nx, nu, N)) {
+            const char *env = getenv("LQMPC_NWIDE");          // tuning knob for experiments
+            long long nw = env ? atoll(env) : (Bsz / 128 < 512 ? Bsz / 128 : 512);   // measured optimum at C3: 512 of 65536
+            p.nwide = nw < 0 ? 0 : (nw > Bsz ? Bsz : nw);
+        }
     }
     return launch(h, p);
 }

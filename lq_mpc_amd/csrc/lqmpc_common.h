@@ -33,6 +33,7 @@ struct KParams {
     double *key;                          // MODE_PROBE output: difficulty key per instance
     double *stage;                        // MODE_PROBE output: instance-major [A|B|x0] records (null: none)
     const double *rec;                    // input records staged by the probe (null: read A, B, x0 directly)
+    long long nwide;                      // tiered rollout: the first nwide slots of the order get a wavefront each
 };
 
 // ---- fp64 reciprocal / reciprocal square root: hardware seed + Newton steps ----

@@ -18,6 +18,7 @@
 // Restates /root/reference/utils_class.py:48-91 (solve) and 245-285 (simulate); the solver replaces cvxpy's
 // QP back-end (utils_class.py:84-88).
 #include "lqmpc_common.h"
+#include <cstdlib>
 
 #include <type_traits>
 
@@ -735,13 +736,13 @@ struct Spec {
 #define LDB(e) (p.rec ? p.rec[b * REC + NX * NX + (e)] : LD(p.B, e))
 #define LDX(e) (p.rec ? p.rec[b * REC + NX * NX + NX * NU + (e)] : LD(p.x0, e))
 
+// One wavefront's work: the SPW instances in slots slot0 .. slot0 + SPW - 1 (slots >= slot_end are surplus).
 template <int NX, int NU, int N, int LPS, int MODE>
-__global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
+__device__ __forceinline__ void spec_body(const KParams &p, double *lds, long long slot0, long long slot_end)
 {
     using S = Spec<NX, NU, N, LPS>;
     constexpr int n = S::n, RB = S::RB, SPW = S::SPW;
     constexpr int REC = NX * NX + NX * NU + NX;      // doubles per staged instance record
-    __shared__ double lds[S::LDS_DOUBLES];
     S st;
     st.lds = lds;
     const int lane = threadIdx.x;
@@ -750,9 +751,9 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
     st.pad = (LPS == 64) && (st.r >= n);
     const int r = st.r, s = st.s;
     const long long Bsz = p.Bsz;
-    const long long b_raw = (long long)blockIdx.x * SPW + s;
-    const bool valid = b_raw < Bsz;
-    const long long slot = valid ? b_raw : Bsz - 1;   // surplus groups recompute the last slot, never store
+    const long long b_raw = slot0 + s;
+    const bool valid = b_raw < slot_end;
+    const long long slot = valid ? b_raw : slot_end - 1;   // surplus groups recompute the last slot, never store
     // processing order: instances sorted by difficulty so that the 16 instances of a wave leave the
     // constrained regime together and the longest waves are dispatched first
     const long long b = p.perm ? (long long)p.perm[slot] : slot;
@@ -1112,6 +1113,31 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
     }
 }
 
+template <int NX, int NU, int N, int LPS, int MODE>
+__global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
+{
+    using S = Spec<NX, NU, N, LPS>;
+    __shared__ double lds[S::LDS_DOUBLES];
+    spec_body<NX, NU, N, LPS, MODE>(p, lds, (long long)blockIdx.x * S::SPW, p.Bsz);
+}
+
+// Two tiers in one launch (sorted rollouts): the p.nwide hardest instances, first in the order, get a whole
+// wavefront each (one matrix row per lane: about a third of the per-iteration latency of the packed layout at
+// 1/16 of its density), everything after them runs packed.  The launch is as long as its slowest wavefront,
+// and that is the wavefront with the instances that stay constrained for all T steps; workgroups dispatch in
+// index order, so the wide ones start first.
+template <int NX, int NU, int N, int LPS, int MODE>
+__global__ void __launch_bounds__(64, 1) lqmpc_spec_tiered_kernel(KParams p)
+{
+    using SW = Spec<NX, NU, N, 64>;
+    using SP = Spec<NX, NU, N, LPS>;
+    constexpr int LDSZ = SW::LDS_DOUBLES > SP::LDS_DOUBLES ? SW::LDS_DOUBLES : SP::LDS_DOUBLES;
+    __shared__ double lds[LDSZ];
+    const long long blk = blockIdx.x;
+    if (blk < p.nwide) spec_body<NX, NU, N, 64, MODE>(p, lds, blk, p.nwide);
+    else spec_body<NX, NU, N, LPS, MODE>(p, lds, p.nwide + (blk - p.nwide) * SP::SPW, p.Bsz);
+}
+
 // ---------------- difficulty probe (options.order) ----------------
 // One instance per lane.  Key = the largest stage gradient of the FREE response over the horizon, in
 // units of what one input can counter:  max_r max_k |B_k' Q A^(r+1) x0| / ((B'QB + R)_kk h_k).
@@ -1193,6 +1219,8 @@ struct SpecEntry {
     int nx, nu, N, lps;
     const char *name;
     void (*launch)(const KParams &, hipStream_t);
+    void (*launch_tiered)(const KParams &, hipStream_t);   // rollouts with p.nwide > 0 (null: not built)
+    const char *name_tiered;
 };
 
 template <int NX, int NU, int N, int LPS>
@@ -1210,12 +1238,22 @@ static void launch_one(const KParams &p, hipStream_t stream)
         hipLaunchKernelGGL((lqmpc_spec_kernel<NX, NU, N, LPS, MODE_ROLLOUT>), dim3(grid), dim3(64), 0, stream, p);
 }
 
-#define SPEC(NX, NU, N, LPS) {NX, NU, N, LPS, "lqmpc_spec_kernel<" #NX "," #NU "," #N "," #LPS ">", launch_one<NX, NU, N, LPS>}
+template <int NX, int NU, int N, int LPS>
+static void launch_tiered(const KParams &p, hipStream_t stream)
+{
+    constexpr int SPW = 64 / LPS;
+    const unsigned grid = (unsigned)(p.nwide + (p.Bsz - p.nwide + SPW - 1) / SPW);
+    hipLaunchKernelGGL((lqmpc_spec_tiered_kernel<NX, NU, N, LPS, MODE_ROLLOUT>), dim3(grid), dim3(64), 0, stream, p);
+}
+
+#define SPEC(NX, NU, N, LPS) {NX, NU, N, LPS, "lqmpc_spec_kernel<" #NX "," #NU "," #N "," #LPS ">", launch_one<NX, NU, N, LPS>, nullptr, nullptr}
+#define SPEC_TIERED(NX, NU, N, LPS) {NX, NU, N, LPS, "lqmpc_spec_kernel<" #NX "," #NU "," #N "," #LPS ">", launch_one<NX, NU, N, LPS>, \
+                                     launch_tiered<NX, NU, N, LPS>, "lqmpc_spec_tiered_kernel<" #NX "," #NU "," #N "," #LPS ">"}
 
 static const SpecEntry g_specs[] = {
     SPEC(2, 1, 5, 1),     // C1  (working_example_single.py shape, N = 5)
     SPEC(2, 1, 10, 2),    // C2
-    SPEC(4, 2, 10, 4),    // C3  (headline)
+    SPEC_TIERED(4, 2, 10, 4),   // C3  (headline)
     SPEC(4, 2, 20, 64),   // C4  (n = 40: one matrix row per lane, a whole wave per instance)
     SPEC(2, 1, 30, 64),   // the reference's N_opc = 30 (V_expert, working_example_multiple.py:35)
     SPEC(2, 1, 20, 4),    // mpc_test.py:12 (N_open = 20)
@@ -1230,11 +1268,17 @@ static const SpecEntry *find_spec(int nx, int nu, int N)
 }
 
 bool spec_available(int nx, int nu, int N) { return find_spec(nx, nu, N) != nullptr; }
+bool spec_tiered_available(int nx, int nu, int N) { const SpecEntry *e = find_spec(nx, nu, N); return e && e->launch_tiered; }
 
 bool launch_spec(const KParams &p, hipStream_t stream, const char **name)
 {
     const SpecEntry *e = find_spec(p.nx, p.nu, p.N);
     if (!e) return false;
+    if (p.nwide > 0 && p.mode == MODE_ROLLOUT && e->launch_tiered) {
+        e->launch_tiered(p, stream);
+        if (name) *name = e->name_tiered;
+        return true;
+    }
     e->launch(p, stream);
     if (name) *name = e->name;
     return true;

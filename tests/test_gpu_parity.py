@@ -266,7 +266,8 @@ def test_data_generation_reproduces_reference_npz(solver, golden_dir):
 
 
 def test_difficulty_ordering_is_transparent(solver, golden_dir):
-    """options.order = 1 (probe + radix sort, hardest first) must not change any instance's result."""
+    """options.order = 1 (probe + radix sort, hardest first; the first instances of the order on a wavefront each)
+    must not change any instance's result beyond the rounding of a different summation order."""
     b = synth.make_batch(3, Bsz=4096 + 37)
     try:
         solver.set_options(order=0)
@@ -277,11 +278,13 @@ def test_difficulty_ordering_is_transparent(solver, golden_dir):
         r2 = solver.rollout_batch(20, *args(b), b["x0"], b["A_true"], b["B_true"], want_traj=True)
     finally:
         solver.set_options(order=-1, presolve=-1, warm_start=-1)
-    for k in ("J_T", "X", "U"):
-        np.testing.assert_array_equal(r0[k], r1[k])          # same algorithm, different order: bit-identical
+    for k in ("J_T", "X", "U"):                                # same algorithm and iterates; the wide tier sums in another order
+        assert np.abs(r0[k] - r1[k]).max() <= 1e-12 * max(1.0, np.abs(r0[k]).max())
+    packed = np.abs(r0["J_T"] - r1["J_T"]) == 0.0
+    assert packed.mean() > 0.9                                # everything outside the wide tier is bit-identical
     # without presolve the interior steps go through the interior-point loop instead: same answers to tolerance
     assert rel(r0["J_T"], r2["J_T"]) < TIGHT and u_err(r0["U"], r2["U"]) < RTOL
-    np.testing.assert_array_equal(r0["iters"], r1["iters"])
+    assert np.mean(r0["iters"] != r1["iters"]) < 1e-3
     assert np.all(r1["status"] == 0) and np.all(r2["status"] == 0)
     idx = np.random.default_rng(1).choice(b["Bsz"], 512, replace=False)
     sub = dict(b, A=np.ascontiguousarray(b["A"][:, :, idx]), B=np.ascontiguousarray(b["B"][:, :, idx]))
