@@ -19,6 +19,9 @@ void launch_generic(const KParams &p, hipStream_t stream);
 bool spec_available(int nx, int nu, int N);
 bool launch_spec(const KParams &p, hipStream_t stream, const char **name);
 bool spec_tiered_available(int nx, int nu, int N);
+// lqmpc_r16.hip: rollouts with one instance per 16-lane row (n <= 32)
+bool r16_available(int nx, int nu, int N);
+bool launch_r16(const KParams &p, hipStream_t stream, const char **name);
 // lqmpc_wg.hip: one instance per workgroup, 32 < n <= 128
 bool wg_supported(const KParams &p, const double *lb, const double *ub);
 bool launch_wg(const KParams &p, hipStream_t stream, const char **name);
@@ -53,6 +56,7 @@ struct lqmpc_handle {
     lqmpc_options opt;
     DevBuf shared, ws;
     DevBuf key, key_sorted, idx, perm, cub_tmp, rec;   // difficulty ordering of rollout batches
+    DevBuf fail;                     // r16 rollouts: [count | list] of the instances handed to the packed kernel
     DevBuf stage[12];                // host-flavour staging (inputs and outputs)
     std::vector<double> shared_host; // last uploaded shared block
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -375,6 +379,32 @@ int lqmpc_rollout_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
     if (true_per_instance) { p.At = A_true; p.Bt = B_true; }
     const bool spec = use_spec(h, nx, nu, N);
     const int order = h->opt.order < 0 ? ((spec && p.presolve && T >= 4 && Bsz >= 1024) ? 1 : 0) : (spec ? h->opt.order : 0);
+    const char *r16env = getenv("LQMPC_R16");                 // experiments: 0 disables the 16-lane-row kernel
+    const bool r16 = spec && h->opt.kernel == LQMPC_KERNEL_AUTO && p.presolve && p.warm_start && lqmpc::r16_available(nx, nu, N) &&
+                     !(r16env && r16env[0] == '0') && Bsz <= INT32_MAX;
+    if (r16) {
+        const int r16_order = h->opt.order < 0 ? ((T >= 4 && Bsz >= 1024) ? 1 : 0) : h->opt.order;
+        if (r16_order) {
+            rc = build_order(h, p);
+            if (rc) return rc;
+        }
+        rc = ensure(h, h->fail, ((size_t)Bsz + 2) * sizeof(int));
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(h->fail.p, 0, 2 * sizeof(int), h->stream));
+        p.fail_count = (int *)h->fail.p;
+        p.fail_list = (int *)h->fail.p + 2;
+        const char *name = nullptr;
+        if (!lqmpc::launch_r16(p, h->stream, &name)) return fail(LQMPC_ERR_UNSUPPORTED, "r16 launch failed");
+        HIP_TRY(hipGetLastError());
+        // second pass: whatever the first one handed back, on the packed kernel, from the start of the rollout
+        KParams f = p;
+        f.perm = p.fail_list; f.count_dev = p.fail_count; f.fail_list = nullptr; f.fail_count = nullptr; f.nwide = 0;
+        const char *name2 = nullptr;
+        if (!lqmpc::launch_spec(f, h->stream, &name2)) return fail(LQMPC_ERR_UNSUPPORTED, "fallback launch failed");
+        HIP_TRY(hipGetLastError());
+        h->last_kernel = name;
+        return 0;
+    }
     if (order) {
         rc = build_order(h, p);
         if (rc) return rc;

@@ -34,6 +34,8 @@ struct KParams {
     double *stage;                        // MODE_PROBE output: instance-major [A|B|x0] records (null: none)
     const double *rec;                    // input records staged by the probe (null: read A, B, x0 directly)
     long long nwide;                      // tiered rollout: the first nwide slots of the order get a wavefront each
+    int *fail_list, *fail_count;          // lqmpc_r16_kernel: instances it hands back (status 3), and their number
+    const int *count_dev;                 // packed kernel as the fallback pass: number of slots to process, on the device
 };
 
 // ---- fp64 reciprocal / reciprocal square root: hardware seed + Newton steps ----

@@ -1118,7 +1118,13 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
 {
     using S = Spec<NX, NU, N, LPS>;
     __shared__ double lds[S::LDS_DOUBLES];
-    spec_body<NX, NU, N, LPS, MODE>(p, lds, (long long)blockIdx.x * S::SPW, p.Bsz);
+    long long slot_end = p.Bsz;
+    if (p.count_dev) {                     // fallback pass over a device-side list: surplus wavefronts leave at once
+        const long long cnt = *p.count_dev;
+        slot_end = cnt < slot_end ? cnt : slot_end;
+        if ((long long)blockIdx.x * S::SPW >= slot_end) return;
+    }
+    spec_body<NX, NU, N, LPS, MODE>(p, lds, (long long)blockIdx.x * S::SPW, slot_end);
 }
 
 // Two tiers in one launch (sorted rollouts): the p.nwide hardest instances, first in the order, get a whole
