@@ -260,6 +260,11 @@ static int prepare(lqmpc_handle *h, const Call &c, KParams &p)
     p.eps = h->opt.eps; p.tau = h->opt.tau; p.z0_scale = h->opt.z0_scale;
     p.Bsz = c.Bsz;
     p.sh = (const double *)h->shared.p;
+    {
+        const char *env = getenv("LQMPC_R16_MAXIT");           // test knob: a small cap exercises the hand-back path
+        p.r16_maxit = env ? atoi(env) : 12;
+        if (p.r16_maxit < 0) p.r16_maxit = 0;
+    }
     if (h->opt.kernel == LQMPC_KERNEL_SPECIALIZED && !lqmpc::spec_available(nx, nu, N))
         return fail(LQMPC_ERR_UNSUPPORTED, "no register-resident specialisation built for these dims");
     h->use_wg = !use_spec(h, nx, nu, N) && (h->opt.kernel == LQMPC_KERNEL_AUTO || h->opt.kernel == LQMPC_KERNEL_WORKGROUP) &&
@@ -379,9 +384,11 @@ int lqmpc_rollout_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
     if (true_per_instance) { p.At = A_true; p.Bt = B_true; }
     const bool spec = use_spec(h, nx, nu, N);
     const int order = h->opt.order < 0 ? ((spec && p.presolve && T >= 4 && Bsz >= 1024) ? 1 : 0) : (spec ? h->opt.order : 0);
-    const char *r16env = getenv("LQMPC_R16");                 // experiments: 0 disables the 16-lane-row kernel
+    // The 16-lane-row kernel on the whole batch is a development switch (LQMPC_R16=1); by default it serves as the
+    // wide tier of the tiered launch below, which is faster.
+    const char *r16env = getenv("LQMPC_R16");
     const bool r16 = spec && h->opt.kernel == LQMPC_KERNEL_AUTO && p.presolve && p.warm_start && lqmpc::r16_available(nx, nu, N) &&
-                     !(r16env && r16env[0] == '0') && Bsz <= INT32_MAX;
+                     (r16env && r16env[0] == '1') && Bsz <= INT32_MAX;
     if (r16) {
         const int r16_order = h->opt.order < 0 ? ((T >= 4 && Bsz >= 1024) ? 1 : 0) : h->opt.order;
         if (r16_order) {
@@ -408,11 +415,27 @@ int lqmpc_rollout_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
     if (order) {
         rc = build_order(h, p);
         if (rc) return rc;
-        // the hardest instances (first in the order) on a wavefront each: see lqmpc_spec_tiered_kernel
-        if (lqmpc::spec_tiered_available(nx, nu, N)) {
+        // the hardest instances (first in the order) in the 16-lane-row layout: see lqmpc_spec_tiered_kernel
+        if (lqmpc::spec_tiered_available(nx, nu, N) && p.presolve && p.warm_start && Bsz <= INT32_MAX) {
             const char *env = getenv("LQMPC_NWIDE");          // tuning knob for experiments
-            long long nw = env ? atoll(env) : (Bsz / 128 < 512 ? Bsz / 128 : 512);   // measured optimum at C3: 512 of 65536
+            long long nw = env ? atoll(env) : (Bsz / 32) / 4 * 4;   // measured optimum at C3: 2048 .. 4096 of 65536
             p.nwide = nw < 0 ? 0 : (nw > Bsz ? Bsz : nw);
+        }
+        if (p.nwide > 0) {
+            rc = ensure(h, h->fail, ((size_t)Bsz + 2) * sizeof(int));
+            if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(h->fail.p, 0, 2 * sizeof(int), h->stream));
+            p.fail_count = (int *)h->fail.p;
+            p.fail_list = (int *)h->fail.p + 2;
+            rc = launch(h, p);
+            if (rc) return rc;
+            const char *name = h->last_kernel;
+            // second pass: whatever the wide tier handed back (status 3), packed, from the start of the rollout
+            KParams f = p;
+            f.perm = p.fail_list; f.count_dev = p.fail_count; f.fail_list = nullptr; f.fail_count = nullptr; f.nwide = 0;
+            rc = launch(h, f);
+            h->last_kernel = name;
+            return rc;
         }
     }
     return launch(h, p);

@@ -36,6 +36,7 @@ struct KParams {
     long long nwide;                      // tiered rollout: the first nwide slots of the order get a wavefront each
     int *fail_list, *fail_count;          // lqmpc_r16_kernel: instances it hands back (status 3), and their number
     const int *count_dev;                 // packed kernel as the fallback pass: number of slots to process, on the device
+    int r16_maxit;                        // active-set iteration cap of the 16-lane-row layout before it hands an instance back
 };
 
 // ---- fp64 reciprocal / reciprocal square root: hardware seed + Newton steps ----

@@ -1,0 +1,637 @@
+// lqmpc_r16_body.h -- device code of the 16-lane-row rollout (see lqmpc_r16.hip for the description);
+// shared by the stand-alone kernel there and by the tiered launch in lqmpc_spec.hip.
+#pragma once
+#include "lqmpc_wg_linalg.h"
+#include <cstdio>
+#include <utility>
+
+namespace lqmpc {
+
+using wg::ldsd;
+using wg::ldsi;
+using wg::rowb;
+using wg::fmac_rowb;
+using wg::fmac_rowb_self;
+using wg::dpp_settle;
+
+#ifdef LQMPC_R16_PROF
+__device__ long long g_r16_prof[16];
+#define RPROF(k) do { const long long now_ = clock64(); if (threadIdx.x == 0 && blockIdx.x == PROFBLK) g_r16_prof[k] += now_ - prof_t; prof_t = clock64(); } while (0)
+#define RPROF_START long long prof_t = clock64()
+#ifndef PROFBLK
+#define PROFBLK 0
+#endif
+#else
+#define RPROF(k) do { } while (0)
+#define RPROF_START do { } while (0)
+#endif
+
+template <int NX, int NU, int N>
+struct R16 {
+    static constexpr int n = N * NU;
+    static constexpr int RB = (n + 15) / 16;
+    static constexpr int LDW = n + 1;                // row stride of P and W: odd, so that a column read is conflict-free
+    static constexpr int PK = n * LDW;               // both stored in full: every access below is row base + constant
+    static constexpr int VEC = 16 * RB;
+    // LDS per instance, in doubles: P | W | vu | r | x | y | list (16 ints)
+    static constexpr int oP = 0, oW = PK, oVU = 2 * PK, oR = oVU + VEC, oX = oR + VEC, oY = oX + VEC, oL = oY + VEC;
+    static constexpr int SETUP = oW + 3 * n * NX + N * NX * NX;          // condensing tables alias the W region and what follows
+    static constexpr int INST = (oL + 8 > SETUP) ? oL + 8 : SETUP;
+    static constexpr int MAXIT = 12;
+    static_assert(n <= 32, "one or two row slots per lane");
+};
+
+
+// One pivot of the in-place Gauss-Jordan inversion (K is a template parameter so that every register index and
+// DPP control below is a constant: the optimizer does not fully unroll a loop of this size on its own).
+template <int K, int RB, int n>
+__device__ __forceinline__ void gj_invert_step(double (&M)[RB][n], const int (&rw)[RB], bool &spd)
+{
+    constexpr int sk = K / 16, lk = K % 16;
+    dpp_settle(M[sk][K]);
+    const double d = rowb(M[sk][K], lk);
+    spd = spd && (d > 0.0);
+    const double inv = frcp(d);
+    double g[RB];
+#pragma unroll
+    for (int s = 0; s < RB; ++s) {
+        const bool isk = (rw[s] == K);
+        g[s] = isk ? (inv - 1.0) : -M[s][K] * inv;
+        M[s][K] = isk ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+#pragma unroll
+        for (int s = 0; s < RB; ++s)
+            if (s != sk) fmac_rowb(M[s][j], M[sk][j], g[s], lk);     // the pivot row's own slot last: it rescales the row the others read
+        if (j == K) fmac_rowb(M[sk][j], M[sk][j], g[sk], lk);       // (column K was written just above: DPP wait states)
+        else fmac_rowb_self(M[sk][j], g[sk], lk);
+    }
+}
+template <int RB, int n, int... K>
+__device__ __forceinline__ void gj_invert(double (&M)[RB][n], const int (&rw)[RB], bool &spd, std::integer_sequence<int, K...>)
+{
+    (gj_invert_step<K, RB, n>(M, rw, spd), ...);
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, CNT - 1>)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int CNT, typename F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, CNT>{}); }
+
+// the 16 bits of a wave ballot that belong to my 16-lane row
+__device__ __forceinline__ unsigned ballot16(bool c, int q) { return (unsigned)((__ballot(c) >> (16 * q)) & 0xFFFFull); }
+
+// One wavefront's work: the four instances in slots slot0 .. slot0 + 3 (slots >= slot_end are surplus).
+template <int NX, int NU, int N>
+__device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long long slot0, long long slot_end)
+{
+    using C = R16<NX, NU, N>;
+    constexpr int n = C::n, RB = C::RB, LDW = C::LDW;
+    constexpr int REC = NX * NX + NX * NU + NX;
+    const int lane = threadIdx.x, q = lane >> 4, i = lane & 15;
+    ldsd *L = (ldsd *)lds_raw + q * C::INST;
+    ldsd *Pp = L + C::oP, *Wp = L + C::oW, *vuL = L + C::oVU, *rL = L + C::oR, *xL = L + C::oX, *yL = L + C::oY;
+    ldsi *list = (ldsi *)(L + C::oL);
+    const long long Bsz = p.Bsz;
+    const long long b_raw = slot0 + q;
+    const bool valid = b_raw < slot_end;
+    const long long slot = valid ? b_raw : slot_end - 1;
+    const long long b = p.perm ? (long long)p.perm[slot] : slot;
+    const double *sh = p.sh;
+    const unsigned nmask = (n == 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
+
+    int rw[RB];
+    bool vrow[RB];
+    double h[RB], ctr[RB];
+#pragma unroll
+    for (int s = 0; s < RB; ++s) {
+        rw[s] = i + 16 * s;
+        vrow[s] = rw[s] < n;
+        const int k = rw[s] % NU;
+        h[s] = vrow[s] ? 0.5 * (sh[p.so.ub + k] - sh[p.so.lb + k]) : 1.0;
+        ctr[s] = vrow[s] ? 0.5 * (sh[p.so.ub + k] + sh[p.so.lb + k]) : 0.0;
+    }
+
+    // ---------------- condensing (utils_class.py:62-75 in matrix form) ----------------
+    // Row i = bi*NU + ui has a = N-1-bi stages to go; with ma_i = column ui of M_a = A^a B,
+    //   H(i, j) = sum_{s>=0} T(i + s NU, j + s NU),   T(i, j) = ma_i . (P_T ma_j) + ma_{i+NU} . ((Q - P_T) ma_{j+NU}),
+    //   Fq(i, :) = 2 [ (P_T ma_i)' A^N + sum_{d>=1} (Q ma_{i+d NU})' A^(N-d) ]
+    // (the displacement structure of Gamma'Qbar Gamma): O(n^2 NX) work and no accumulator matrix carried through
+    // a loop.  The row images ma, P_T ma, Q ma and the powers of A sit in LDS (the W region and the vectors
+    // behind it, free until the inverse is stored).
+    double G[RB][NX], vr[RB];
+    {
+        RPROF_START;
+        ldsd *MA = Wp, *PM = MA + n * NX, *QM = PM + n * NX, *AP = QM + n * NX;
+        double A[NX][NX], Bm[NX][NU];
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+#pragma unroll
+            for (int c = 0; c < NX; ++c) A[a][c] = p.rec ? p.rec[b * REC + a * NX + c] : p.A[(long long)(a * NX + c) * Bsz + b];
+#pragma unroll
+            for (int k = 0; k < NU; ++k) Bm[a][k] = p.rec ? p.rec[b * REC + NX * NX + a * NU + k] : p.B[(long long)(a * NU + k) * Bsz + b];
+        }
+        double ma[RB][NX];
+#pragma unroll
+        for (int s = 0; s < RB; ++s)
+#pragma unroll
+            for (int a = 0; a < NX; ++a) ma[s][a] = 0.0;
+        {   // every lane runs the chains M_m = A^m B and A^(m+1); rows capture their column, lane e % 16 stores element e of A^(m+1)
+            double Mc[NX][NU], Ap[NX][NX];
+#pragma unroll
+            for (int a = 0; a < NX; ++a) {
+#pragma unroll
+                for (int k = 0; k < NU; ++k) Mc[a][k] = Bm[a][k];
+#pragma unroll
+                for (int c = 0; c < NX; ++c) Ap[a][c] = A[a][c];
+            }
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                if (m > 0) {
+                    double T[NX][NU], T2[NX][NX];
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) {
+#pragma unroll
+                        for (int k = 0; k < NU; ++k) {
+                            double t = 0.0;
+#pragma unroll
+                            for (int c = 0; c < NX; ++c) t = __builtin_fma(A[a][c], Mc[c][k], t);
+                            T[a][k] = t;
+                        }
+#pragma unroll
+                        for (int k = 0; k < NX; ++k) {
+                            double t = 0.0;
+#pragma unroll
+                            for (int c = 0; c < NX; ++c) t = __builtin_fma(A[a][c], Ap[c][k], t);
+                            T2[a][k] = t;
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) {
+#pragma unroll
+                        for (int k = 0; k < NU; ++k) Mc[a][k] = T[a][k];
+#pragma unroll
+                        for (int k = 0; k < NX; ++k) Ap[a][k] = T2[a][k];
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < RB; ++s) {
+                    const bool mine = vrow[s] && (rw[s] / NU == N - 1 - m);
+#pragma unroll
+                    for (int k = 0; k < NU; ++k)
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) ma[s][a] = (mine && rw[s] % NU == k) ? Mc[a][k] : ma[s][a];
+                }
+#pragma unroll
+                for (int e = 0; e < NX * NX; ++e)
+                    if ((e & 15) == i) AP[m * NX * NX + e] = Ap[e / NX][e % NX];      // AP[m] = A^(m+1)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        RPROF(0);
+        double pm[RB][NX];
+#pragma unroll
+        for (int s = 0; s < RB; ++s) {
+#pragma unroll
+            for (int a = 0; a < NX; ++a) {
+                double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+                for (int c = 0; c < NX; ++c) {
+                    t1 = __builtin_fma(sh[p.so.P + a * NX + c], ma[s][c], t1);
+                    t2 = __builtin_fma(sh[p.so.Q + a * NX + c], ma[s][c], t2);
+                }
+                pm[s][a] = t1;
+                if (vrow[s]) { MA[rw[s] * NX + a] = ma[s][a]; PM[rw[s] * NX + a] = t1; QM[rw[s] * NX + a] = t2; }
+            }
+        }
+        __syncthreads();
+        // T(i, j), j <= i, into the packed P region
+#pragma unroll
+        for (int s = 0; s < RB; ++s) {
+            const bool nxt = vrow[s] && rw[s] + NU < n;
+            double man[NX];
+#pragma unroll
+            for (int a = 0; a < NX; ++a) man[a] = nxt ? MA[(rw[s] + NU) * NX + a] : 0.0;
+#pragma unroll
+            for (int j = 0; j < n; ++j) {
+                if (j > 16 * s + 15) continue;                   // static: no row of this slot reaches column j
+                double t = 0.0;
+#pragma unroll
+                for (int a = 0; a < NX; ++a) t = __builtin_fma(ma[s][a], PM[j * NX + a], t);
+                if (j + NU < n) {
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) t = __builtin_fma(man[a], QM[(j + NU) * NX + a] - PM[(j + NU) * NX + a], t);
+                }
+                if (vrow[s] && j <= rw[s]) Pp[rw[s] * LDW + j] = t;
+                if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // straight-line code: keep the loads near their use
+            }
+        }
+        __syncthreads();
+        RPROF(1);
+        // H = suffix sums of T along the stage diagonals; P = 2 (H + Rbar)
+        double Wr[RB][n];
+#pragma unroll
+        for (int s = 0; s < RB; ++s) {
+#pragma unroll
+            for (int j = 0; j < n; ++j) {
+                double acc = 0.0;
+                if (j <= 16 * s + 15) {
+#pragma unroll
+                    for (int d = 0; d < N; ++d) {
+                        if (16 * s + d * NU >= n) continue;      // static: beyond the last row for every row of this slot
+                        const bool in = vrow[s] && j <= rw[s] && rw[s] + d * NU < n;
+                        const double t = Pp[in ? (rw[s] + d * NU) * LDW + j + d * NU : 0];
+                        acc += in ? t : 0.0;
+                    }
+                }
+                Wr[s][j] = acc;
+                if (j % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < RB; ++s) {
+            const int bi = rw[s] / NU, ui = rw[s] % NU;
+#pragma unroll
+            for (int j = 0; j < n; ++j) {
+                if (j > 16 * s + 15) continue;
+                const double val = 2.0 * (Wr[s][j] + ((j / NU == bi) ? sh[p.so.R + ui * NU + (j % NU)] : 0.0));
+                Wr[s][j] = val;
+                if (vrow[s] && j <= rw[s]) Pp[rw[s] * LDW + j] = val;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < RB; ++s)
+#pragma unroll
+            for (int j = 0; j < n; ++j) {
+                const double up = Pp[(vrow[s] && j > rw[s]) ? j * LDW + rw[s] : 0];
+                Wr[s][j] = vrow[s] ? ((j > rw[s]) ? up : Wr[s][j]) : 0.0;
+                if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < RB; ++s)
+#pragma unroll
+            for (int j = 0; j < n; ++j)
+                if (vrow[s] && j > rw[s]) Pp[rw[s] * LDW + j] = Wr[s][j];          // the upper triangle: rows are stored in full
+        RPROF(2);
+        // Fq rows
+        double Facc[RB][NX];
+#pragma unroll
+        for (int s = 0; s < RB; ++s) {
+#pragma unroll
+            for (int c = 0; c < NX; ++c) {
+                double t = 0.0;
+#pragma unroll
+                for (int a = 0; a < NX; ++a) t = __builtin_fma(pm[s][a], AP[(N - 1) * NX * NX + a * NX + c], t);
+                Facc[s][c] = t;
+            }
+#pragma unroll
+            for (int d = 1; d < N; ++d) {
+                if (16 * s + d * NU >= n) continue;              // static
+                const bool in = vrow[s] && rw[s] + d * NU < n;
+                double wmv[NX];
+#pragma unroll
+                for (int a = 0; a < NX; ++a) wmv[a] = in ? QM[(rw[s] + d * NU) * NX + a] : 0.0;
+#pragma unroll
+                for (int c = 0; c < NX; ++c) {
+                    double t = Facc[s][c];
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) t = __builtin_fma(wmv[a], AP[(N - 1 - d) * NX * NX + a * NX + c], t);
+                    Facc[s][c] = t;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int c = 0; c < NX; ++c) Facc[s][c] = vrow[s] ? 2.0 * Facc[s][c] : 0.0;
+        }
+        RPROF(3);
+        // constant part of the linear term: qr = 2 gref + P centre (references / off-centre boxes only)
+        bool has_lin = p.has_ref != 0;
+#pragma unroll
+        for (int k = 0; k < NU; ++k) has_lin = has_lin || (sh[p.so.ub + k] + sh[p.so.lb + k] != 0.0);
+        double qr[RB];
+#pragma unroll
+        for (int s = 0; s < RB; ++s) qr[s] = 0.0;
+        if (has_lin) {
+            if (p.has_ref) {
+                //   d_r = -xref_r,  lam_r = Q_r d_r + A' lam_{r+1},  gref_r = B' lam_r - R uref_r   (columns r <-> x_{r+1}, u_r)
+                double lam[NX];
+#pragma unroll
+                for (int a = 0; a < NX; ++a) lam[a] = 0.0;
+#pragma unroll 1
+                for (int r = N - 1; r >= 0; --r) {
+                    const int oQ = (r < N - 1) ? p.so.Q : p.so.P;
+                    double l2[NX];
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int c = 0; c < NX; ++c) t = __builtin_fma(sh[oQ + a * NX + c], -sh[p.so.xref + c * N + r], t);
+#pragma unroll
+                        for (int c = 0; c < NX; ++c) t = __builtin_fma(A[c][a], lam[c], t);
+                        l2[a] = t;
+                    }
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) lam[a] = l2[a];
+#pragma unroll
+                    for (int s = 0; s < RB; ++s) {
+                        const int ui = rw[s] % NU;
+                        double t = 0.0;
+#pragma unroll
+                        for (int k = 0; k < NU; ++k) {
+                            double tk = 0.0;
+#pragma unroll
+                            for (int a = 0; a < NX; ++a) tk = __builtin_fma(Bm[a][k], lam[a], tk);
+#pragma unroll
+                            for (int j = 0; j < NU; ++j) tk = __builtin_fma(-sh[p.so.R + k * NU + j], sh[p.so.uref + j * N + r], tk);
+                            t = (ui == k) ? tk : t;
+                        }
+                        qr[s] = (vrow[s] && rw[s] / NU == r) ? 2.0 * t : qr[s];
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < RB; ++s) {
+                double t = qr[s];
+#pragma unroll
+                for (int j = 0; j < n; ++j) t = __builtin_fma(Wr[s][j], 0.5 * (sh[p.so.ub + j % NU] + sh[p.so.lb + j % NU]), t);
+                qr[s] = vrow[s] ? t : 0.0;
+            }
+        }
+        __syncthreads();                       // the tables in the W region are dead from here
+        __builtin_amdgcn_sched_barrier(0);
+        // W = P^-1 by Gauss-Jordan elimination in place: per pivot k the pivot row reaches every lane through
+        // the DPP operand of the update, row_i += g_i * row_k with g_i = -a_ik / a_kk (g_k = 1/a_kk - 1 scales
+        // the pivot row itself); column k is set to e_k first so that it ends up holding column k of the inverse.
+        bool spd = true;
+        RPROF(4);
+        gj_invert<RB, n>(Wr, rw, spd, std::make_integer_sequence<int, n>{});
+        RPROF(5);
+        // [G | v_r] = -W [Fq | qr]: row i of W is in my registers, row j of [Fq | qr] comes by row broadcast
+#pragma unroll
+        for (int s = 0; s < RB; ++s) {
+            vr[s] = 0.0;
+#pragma unroll
+            for (int a = 0; a < NX; ++a) G[s][a] = 0.0;
+        }
+        static_for<n>([&](auto jc) {                        // (a plain loop with the DPP switch inside is not fully unrolled)
+            constexpr int j = decltype(jc)::value, sj = j / 16, lj = j % 16;
+#pragma unroll
+            for (int s = 0; s < RB; ++s) {
+                const double nw = -Wr[s][j];
+#pragma unroll
+                for (int a = 0; a < NX; ++a) fmac_rowb(G[s][a], Facc[sj][a], nw, lj);
+                if (has_lin) fmac_rowb(vr[s], qr[sj], nw, lj);
+            }
+        });
+#pragma unroll
+        for (int s = 0; s < RB; ++s) {
+#pragma unroll
+            for (int j = 0; j < n; ++j)
+                if (vrow[s]) Wp[rw[s] * LDW + j] = Wr[s][j];
+            if (!vrow[s]) {
+                vr[s] = 0.0;
+#pragma unroll
+                for (int a = 0; a < NX; ++a) G[s][a] = 0.0;
+            }
+        }
+        if (!spd) {
+#pragma unroll
+            for (int s = 0; s < RB; ++s) vr[s] = __builtin_nan("");
+        }
+        __syncthreads();
+        RPROF(6);
+    }
+    RPROF_START;
+
+    // ---------------- closed loop (utils_class.py:266-283) ----------------
+    double x[NX];
+#pragma unroll
+    for (int a = 0; a < NX; ++a) x[a] = p.rec ? p.rec[b * REC + NX * NX + NX * NU + a] : p.x0[(long long)a * Bsz + b];
+    // stage weights and the plant once: inside the step loop they would be 22 vector loads per step
+    double Qm[NX][NX], Rm[NU][NU], Atm[NX][NX], Btm[NX][NU];
+#pragma unroll
+    for (int a = 0; a < NX; ++a) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+            Qm[a][c] = sh[p.so.Q + a * NX + c];
+            Atm[a][c] = p.true_per_instance ? p.At[(long long)(a * NX + c) * Bsz + b] : sh[p.so.At + a * NX + c];
+        }
+#pragma unroll
+        for (int k = 0; k < NU; ++k) Btm[a][k] = p.true_per_instance ? p.Bt[(long long)(a * NU + k) * Bsz + b] : sh[p.so.Bt + a * NU + k];
+    }
+#pragma unroll
+    for (int k = 0; k < NU; ++k)
+#pragma unroll
+        for (int j = 0; j < NU; ++j) Rm[k][j] = sh[p.so.R + k * NU + j];
+    double cost = 0.0;
+#pragma unroll
+    for (int a = 0; a < NX; ++a)
+#pragma unroll
+        for (int c = 0; c < NX; ++c) cost = __builtin_fma(x[a] * Qm[a][c], x[c], cost);
+    const bool writer = valid && i == 0;
+    if (p.X && writer) {
+#pragma unroll
+        for (int a = 0; a < NX; ++a) p.X[((long long)a * (p.T + 1)) * Bsz + b] = x[a];
+    }
+    unsigned pL = 0, pU = 0;                  // active set of the previous step (row-uniform bit masks)
+    int iters = 0, status = 0;
+    for (int t = 0; t < p.T; ++t) {
+        double vu[RB], v[RB];
+        unsigned cl = 0, cu = 0;
+        bool bad = false;
+#pragma unroll
+        for (int s = 0; s < RB; ++s) {
+            double acc = vr[s];
+#pragma unroll
+            for (int a = 0; a < NX; ++a) acc = __builtin_fma(G[s][a], x[a], acc);
+            vu[s] = acc; v[s] = acc;
+            cl |= ballot16(vrow[s] && acc < -h[s], q) << (16 * s);
+            cu |= ballot16(vrow[s] && acc > h[s], q) << (16 * s);
+            bad = bad || (vrow[s] && !(fabs(acc) < 1e300));
+        }
+        const bool rowbad = ballot16(bad, q) != 0;
+        bool busy = ((cl | cu) != 0) && !rowbad;              // row-uniform
+        unsigned mL = 0, mU = 0;
+        if (busy) {
+            if (p.warm_start && (pL | pU) != 0) {
+                // the previous face shifted by one stage; the last stage keeps its flags
+                const unsigned top = nmask & ~(nmask >> NU);
+                mL = (pL >> NU) | (pL & top);
+                mU = (pU >> NU) | (pU & top);
+            } else {
+                mL = cl; mU = cu;
+            }
+        }
+        bool failed = false;
+        if (__ballot(busy) != 0ull) {
+#pragma unroll 1
+            for (int it = 0; it < p.r16_maxit; ++it) {
+                const unsigned mA = mL | mU;
+                const int m = __popc(mA);
+                const bool dual = 2 * m <= n;                     // row-uniform: the smaller side
+                const unsigned mC = busy ? (dual ? mA : (~mA & nmask)) : 0u;
+                const int c = __popc(mC);
+                int cw = c;                                      // wave maximum: uniform loop bound
+                cw = max(cw, __shfl_xor(cw, 16)); cw = max(cw, __shfl_xor(cw, 32));
+                cw = __builtin_amdgcn_readfirstlane(cw);
+                const bool any_primal = __ballot(busy && !dual) != 0ull;
+                // publish v_unc, r = v_unc - s h on the active rows (0 elsewhere), the list of the chosen side
+#pragma unroll
+                for (int s = 0; s < RB; ++s) {
+                    const unsigned bit = 1u << rw[s];
+                    const double sg = (mL & bit) ? -1.0 : ((mU & bit) ? 1.0 : 0.0);
+                    vuL[rw[s]] = vu[s];
+                    rL[rw[s]] = (sg != 0.0) ? vu[s] - sg * h[s] : 0.0;
+                    xL[rw[s]] = 0.0;
+                    if (vrow[s] && (mC & bit)) list[__popc(mC & (bit - 1u))] = rw[s];
+                }
+                __syncthreads();
+                const ldsd *Mx = dual ? Wp : Pp;
+                const int la = (i < c) ? list[i] : 0;
+                double S[16], rhs;
+#pragma unroll
+                for (int bb = 0; bb < 16; ++bb) {
+                    S[bb] = (bb == i) ? 1.0 : 0.0;
+                    if (bb < cw) {                               // uniform
+                        const int lb = (bb < c) ? list[bb] : 0;
+                        const double val = Mx[la * LDW + lb];
+                        if (i < c && bb < c) S[bb] = val;
+                    }
+                }
+                rhs = (i < c && dual) ? rL[la] : 0.0;
+                if (any_primal) {
+                    double tp = 0.0;
+#pragma unroll
+                    for (int j = 0; j < n; ++j) tp = __builtin_fma(Pp[la * LDW + j], rL[j], tp);
+                    if (i < c && !dual) rhs = tp;
+                }
+                // Gauss-Jordan on [S | rhs]: afterwards S = I and rhs = the solution
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (k < cw) {                                // uniform
+                        dpp_settle(S[k]);
+                        const double d = rowb(S[k], k);
+                        ok = ok && (d > 0.0);
+                        const double inv = frcp(d);
+                        const double g = (i == k) ? (inv - 1.0) : -S[k] * inv;
+#pragma unroll
+                        for (int j = k + 1; j < 16; ++j)
+                            if (j < cw) fmac_rowb_self(S[j], g, k);
+                        fmac_rowb_self(rhs, g, k);
+                    }
+                }
+                const bool rowfail = ballot16(!ok, q) != 0;
+                if (i < c) xL[la] = rhs;
+                __syncthreads();
+                double xs_[RB];
+#pragma unroll
+                for (int s = 0; s < RB; ++s) {                   // y = x (dual side) or x - r (primal side): what the matrix row multiplies
+                    xs_[s] = xL[rw[s]];
+                    yL[rw[s]] = dual ? xs_[s] : xs_[s] - rL[rw[s]];
+                }
+                __syncthreads();
+                // t = (M y)_row with y = x (dual, M = W) or x - r (primal, M = P); x is zero off the chosen side
+                double tol = 0.0, gl[RB];
+#pragma unroll
+                for (int s = 0; s < RB; ++s) {
+                    double tt = 0.0;
+                    const ldsd *Mrow = Mx + (vrow[s] ? rw[s] : 0) * LDW;
+#pragma unroll
+                    for (int j = 0; j < n; ++j) tt = __builtin_fma(Mrow[j], yL[j], tt);
+                    const unsigned bit = 1u << rw[s];
+                    const bool act = vrow[s] && (mA & bit);
+                    const double sg = (mL & bit) ? -1.0 : 1.0;
+                    const double xs = xs_[s];
+                    // free rows: the new value; active rows: the bound, and the gradient there (rows that are done keep theirs)
+                    const double nv = act ? sg * h[s] : (dual ? vu[s] - tt : vu[s] + xs);
+                    v[s] = busy ? nv : v[s];
+                    gl[s] = act ? (dual ? -xs : tt) : 0.0;
+                    tol = fmax(tol, fabs(gl[s]));
+                }
+                tol = fmax(tol, __shfl_xor(tol, 1)); tol = fmax(tol, __shfl_xor(tol, 2));
+                tol = fmax(tol, __shfl_xor(tol, 4)); tol = fmax(tol, __shfl_xor(tol, 8));
+                tol *= 1e-10;
+                unsigned nL = 0, nU = 0;
+                bool nf = false;
+#pragma unroll
+                for (int s = 0; s < RB; ++s) {
+                    const unsigned bit = 1u << rw[s];
+                    const bool act = vrow[s] && (mA & bit);
+                    const bool lo = act ? ((mL & bit) && gl[s] >= -tol) : (vrow[s] && v[s] < -h[s] * (1.0 + 1e-12));
+                    const bool up = act ? ((mU & bit) && gl[s] <= tol) : (vrow[s] && v[s] > h[s] * (1.0 + 1e-12));
+                    nL |= ballot16(lo, q) << (16 * s);
+                    nU |= ballot16(up, q) << (16 * s);
+                    nf = nf || (vrow[s] && !(fabs(v[s]) < 1e300));
+                }
+                const bool rownf = ballot16(nf, q) != 0;
+                if (busy) {
+                    iters += 1;
+                    if (rowfail || rownf) { failed = true; busy = false; }
+                    else if (nL == mL && nU == mU) busy = false;
+                    else { mL = nL; mU = nU; }
+                }
+                __syncthreads();
+                if (__ballot(busy) == 0ull) break;
+            }
+        }
+        if (busy) failed = true;
+        if (failed || rowbad) {
+            status = 3; pL = 0; pU = 0;
+#pragma unroll
+            for (int s = 0; s < RB; ++s) v[s] = fmin(fmax(vu[s], -h[s]), h[s]);
+        } else {
+            pL = mL; pU = mU;
+        }
+        // u_k = clipped v of row k + centre, from lane k of the row
+        double u[NU], xn[NX];
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            const double uk = fmin(fmax(v[k / 16], -h[k / 16]), h[k / 16]) + ctr[k / 16];
+            u[k] = rowb(uk, k % 16);
+        }
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < NX; ++c) acc = __builtin_fma(Atm[a][c], x[c], acc);
+#pragma unroll
+            for (int k = 0; k < NU; ++k) acc = __builtin_fma(Btm[a][k], u[k], acc);
+            xn[a] = acc;
+        }
+#pragma unroll
+        for (int a = 0; a < NX; ++a) x[a] = xn[a];
+#pragma unroll
+        for (int a = 0; a < NX; ++a)
+#pragma unroll
+            for (int c = 0; c < NX; ++c) cost = __builtin_fma(xn[a] * Qm[a][c], xn[c], cost);
+#pragma unroll
+        for (int k = 0; k < NU; ++k)
+#pragma unroll
+            for (int j = 0; j < NU; ++j) cost = __builtin_fma(u[k] * Rm[k][j], u[j], cost);
+        if (writer) {
+            if (p.X) {
+#pragma unroll
+                for (int a = 0; a < NX; ++a) p.X[((long long)a * (p.T + 1) + t + 1) * Bsz + b] = xn[a];
+            }
+            if (p.U) {
+#pragma unroll
+                for (int k = 0; k < NU; ++k) p.U[((long long)k * p.T + t) * Bsz + b] = u[k];
+            }
+        }
+    }
+    RPROF(7);
+    if (writer) {
+        p.JT[b] = cost;
+        if (p.status) p.status[b] = status;
+        if (p.iters) p.iters[b] = iters;
+        if (status == 3 && p.fail_list) p.fail_list[atomicAdd(p.fail_count, 1)] = (int)b;
+    }
+}
+
+}  // namespace lqmpc

@@ -18,6 +18,7 @@
 // Restates /root/reference/utils_class.py:48-91 (solve) and 245-285 (simulate); the solver replaces cvxpy's
 // QP back-end (utils_class.py:84-88).
 #include "lqmpc_common.h"
+#include "lqmpc_r16_body.h"
 #include <cstdlib>
 
 #include <type_traits>
@@ -1127,21 +1128,22 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
     spec_body<NX, NU, N, LPS, MODE>(p, lds, (long long)blockIdx.x * S::SPW, slot_end);
 }
 
-// Two tiers in one launch (sorted rollouts): the p.nwide hardest instances, first in the order, get a whole
-// wavefront each (one matrix row per lane: about a third of the per-iteration latency of the packed layout at
-// 1/16 of its density), everything after them runs packed.  The launch is as long as its slowest wavefront,
-// and that is the wavefront with the instances that stay constrained for all T steps; workgroups dispatch in
-// index order, so the wide ones start first.
+// Two tiers in one launch (sorted rollouts).  The launch is as long as its slowest wavefront, and in the packed
+// layout that is the wavefront with the instances that stay constrained for all T steps: 16 instances, ~4000
+// instructions per active-set iteration, up to 78 iterations at C3.  So the p.nwide hardest instances, first
+// in the order, run in the 16-lane-row layout of lqmpc_r16_body.h (four per wavefront, a few hundred
+// instructions per iteration because only the smaller side of the active-set system is solved), everything
+// after them runs packed.  Workgroups dispatch in index order, so the hard ones start first.
 template <int NX, int NU, int N, int LPS, int MODE>
 __global__ void __launch_bounds__(64, 1) lqmpc_spec_tiered_kernel(KParams p)
 {
-    using SW = Spec<NX, NU, N, 64>;
     using SP = Spec<NX, NU, N, LPS>;
-    constexpr int LDSZ = SW::LDS_DOUBLES > SP::LDS_DOUBLES ? SW::LDS_DOUBLES : SP::LDS_DOUBLES;
+    constexpr int R16SZ = 4 * R16<NX, NU, N>::INST;
+    constexpr int LDSZ = R16SZ > SP::LDS_DOUBLES ? R16SZ : SP::LDS_DOUBLES;
     __shared__ double lds[LDSZ];
-    const long long blk = blockIdx.x;
-    if (blk < p.nwide) spec_body<NX, NU, N, 64, MODE>(p, lds, blk, p.nwide);
-    else spec_body<NX, NU, N, LPS, MODE>(p, lds, p.nwide + (blk - p.nwide) * SP::SPW, p.Bsz);
+    const long long blk = blockIdx.x, nb16 = (p.nwide + 3) / 4;
+    if (blk < nb16) r16_body<NX, NU, N>(p, lds, blk * 4, p.nwide);
+    else spec_body<NX, NU, N, LPS, MODE>(p, lds, p.nwide + (blk - nb16) * SP::SPW, p.Bsz);
 }
 
 // ---------------- difficulty probe (options.order) ----------------
@@ -1248,7 +1250,7 @@ template <int NX, int NU, int N, int LPS>
 static void launch_tiered(const KParams &p, hipStream_t stream)
 {
     constexpr int SPW = 64 / LPS;
-    const unsigned grid = (unsigned)(p.nwide + (p.Bsz - p.nwide + SPW - 1) / SPW);
+    const unsigned grid = (unsigned)((p.nwide + 3) / 4 + (p.Bsz - p.nwide + SPW - 1) / SPW);
     hipLaunchKernelGGL((lqmpc_spec_tiered_kernel<NX, NU, N, LPS, MODE_ROLLOUT>), dim3(grid), dim3(64), 0, stream, p);
 }
 

@@ -97,6 +97,22 @@ __device__ __forceinline__ void fmac_rowb(double &acc, double x, double y, int c
     }
 }
 
+// acc += (lane c's acc, broadcast over the row) * y: the elimination update, source and destination one operand.
+// (Dropping the s_nop here was tried and is wrong on gfx950: under register pressure the compiler copies or
+// reloads the operand right before the statement, and a DPP read two slots after a VALU write returns stale data.)
+__device__ __forceinline__ void fmac_rowb_self(double &acc, double y, int c)
+{
+    switch (c) {
+#define LQMPC_X(C) case C: asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:" #C " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(y)); break;
+        LQMPC_ROWB_CASES(LQMPC_X)
+#undef LQMPC_X
+    }
+}
+
+// two wait states tied to x: a DPP read of x that follows in program order is safe even if x was written by
+// the inline asm right before (the compiler's hazard recogniser does not see those writes)
+__device__ __forceinline__ void dpp_settle(double &x) { asm volatile("s_nop 1" : "+v"(x)); }
+
 // 1/sqrt(x): v_rsq_f64 (relative error 2^-24 on gfx950, tools/wg_test) + one cubic step -> ~1 ulp
 __device__ __forceinline__ double frsqrt1(double x)
 {

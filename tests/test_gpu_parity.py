@@ -380,3 +380,30 @@ def test_workgroup_kernel_dispatch_and_agreement(solver):
             solver.solve_batch(*args(b3), b3["x0"])             # n = 20: below the kernel's range
     finally:
         solver.set_options(kernel=KERNEL_AUTO)
+
+
+def test_tiered_rollout_wide_tier_and_hand_back(solver, monkeypatch):
+    """Sorted rollouts run their hardest instances in the 16-lane-row layout (lqmpc_r16_body.h).  References,
+    an off-centre box and per-instance plants go through it; with its iteration cap forced to 1 it hands the
+    constrained instances back (status 3 internally) and the packed kernel's second pass must restore every one."""
+    rng = np.random.default_rng(7)
+    nx, nu, N, Bsz, T = 4, 2, 10, 2048, 12
+    b = synth.make_batch(3, Bsz=Bsz)
+    lb, ub = np.array([-0.08, -0.1]), np.array([0.1, 0.05])
+    xr, ur = 0.05 * rng.standard_normal((nx, N)), 0.02 * rng.standard_normal((nu, N))
+    At = np.ascontiguousarray(b["A"] + 0.01 * rng.standard_normal(b["A"].shape))
+    Bt = np.ascontiguousarray(b["B"] + 0.01 * rng.standard_normal(b["B"].shape))
+    a = (N, b["A"], b["B"], b["Q"], b["R"], 3.0 * b["P"], lb, ub)
+    ref = orc.rollout_batch(T, *a, b["x0"], At, Bt, xr, ur, want_traj=True)
+    try:
+        solver.set_options(order=1)
+        for cap, nwide in ((None, "1024"), ("1", "1024"), (None, "2048")):
+            if cap is None: monkeypatch.delenv("LQMPC_R16_MAXIT", raising=False)
+            else: monkeypatch.setenv("LQMPC_R16_MAXIT", cap)
+            monkeypatch.setenv("LQMPC_NWIDE", nwide)
+            g = solver.rollout_batch(T, *a, b["x0"], At, Bt, xr, ur, want_traj=True)
+            assert "tiered" in solver.last_kernel()
+            assert np.all(g["status"] == 0)
+            assert rel(g["J_T"], ref["J_T"]) < TIGHT and u_err(g["U"], ref["U"]) < RTOL and np.abs(g["X"] - ref["X"]).max() < 1e-7
+    finally:
+        solver.set_options(order=-1)

@@ -11,7 +11,8 @@ dA, dB, dx0 = (torch.from_numpy(a).to(dev) for a in (b['A'], b['B'], b['x0']))
 dJ = torch.empty(K, dtype=torch.float64, device=dev); dit = torch.empty(K, dtype=torch.int32, device=dev); dst = torch.empty(K, dtype=torch.int32, device=dev)
 s = BatchSolver(0)
 ref = None
-for nw in (0, 256, 512, 1024, 1536, 2048, 3072, 4096):
+os.environ['LQMPC_R16'] = '0'
+for nw in (0, 1024, 2048, 4096, 8192, 12288, 16384, 24576, 32768):
     os.environ['LQMPC_NWIDE'] = str(nw)
     ts = []
     for rep in range(6):
