@@ -278,36 +278,41 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             for (int j = 0; j < n; ++j)
                 if (vrow[s] && j > rw[s]) Pp[rw[s] * LDW + j] = Wr[s][j];          // the upper triangle: rows are stored in full
         RPROF(2);
-        // Fq rows
+        __builtin_amdgcn_sched_barrier(0);
+        // Fq rows: power by power (d outer), so that each A^(N-d) is fetched once for both row slots
         double Facc[RB][NX];
 #pragma unroll
-        for (int s = 0; s < RB; ++s) {
+        for (int s = 0; s < RB; ++s)
 #pragma unroll
-            for (int c = 0; c < NX; ++c) {
-                double t = 0.0;
+            for (int c = 0; c < NX; ++c) Facc[s][c] = 0.0;
 #pragma unroll
-                for (int a = 0; a < NX; ++a) t = __builtin_fma(pm[s][a], AP[(N - 1) * NX * NX + a * NX + c], t);
-                Facc[s][c] = t;
-            }
+        for (int d = 0; d < N; ++d) {
+            double Apw[NX][NX];
 #pragma unroll
-            for (int d = 1; d < N; ++d) {
-                if (16 * s + d * NU >= n) continue;              // static
+            for (int a = 0; a < NX; ++a)
+#pragma unroll
+                for (int c = 0; c < NX; ++c) Apw[a][c] = AP[(N - 1 - d) * NX * NX + a * NX + c];
+#pragma unroll
+            for (int s = 0; s < RB; ++s) {
+                if (16 * s + d * NU >= n) continue;              // static: beyond the last row for every row of this slot
                 const bool in = vrow[s] && rw[s] + d * NU < n;
                 double wmv[NX];
 #pragma unroll
-                for (int a = 0; a < NX; ++a) wmv[a] = in ? QM[(rw[s] + d * NU) * NX + a] : 0.0;
+                for (int a = 0; a < NX; ++a) wmv[a] = (d == 0) ? pm[s][a] : (in ? QM[(rw[s] + d * NU) * NX + a] : 0.0);
 #pragma unroll
                 for (int c = 0; c < NX; ++c) {
                     double t = Facc[s][c];
 #pragma unroll
-                    for (int a = 0; a < NX; ++a) t = __builtin_fma(wmv[a], AP[(N - 1 - d) * NX * NX + a * NX + c], t);
+                    for (int a = 0; a < NX; ++a) t = __builtin_fma(wmv[a], Apw[a][c], t);
                     Facc[s][c] = t;
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < RB; ++s)
 #pragma unroll
             for (int c = 0; c < NX; ++c) Facc[s][c] = vrow[s] ? 2.0 * Facc[s][c] : 0.0;
-        }
         RPROF(3);
         // constant part of the linear term: qr = 2 gref + P centre (references / off-centre boxes only)
         bool has_lin = p.has_ref != 0;
@@ -319,9 +324,15 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         if (has_lin) {
             if (p.has_ref) {
                 //   d_r = -xref_r,  lam_r = Q_r d_r + A' lam_{r+1},  gref_r = B' lam_r - R uref_r   (columns r <-> x_{r+1}, u_r)
-                double lam[NX];
+                double lam[NX], A2[NX][NX], B2[NX][NU];       // the model again: not kept live across the condensing above
 #pragma unroll
-                for (int a = 0; a < NX; ++a) lam[a] = 0.0;
+                for (int a = 0; a < NX; ++a) {
+                    lam[a] = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NX; ++c) A2[a][c] = p.rec ? p.rec[b * REC + a * NX + c] : p.A[(long long)(a * NX + c) * Bsz + b];
+#pragma unroll
+                    for (int k = 0; k < NU; ++k) B2[a][k] = p.rec ? p.rec[b * REC + NX * NX + a * NU + k] : p.B[(long long)(a * NU + k) * Bsz + b];
+                }
 #pragma unroll 1
                 for (int r = N - 1; r >= 0; --r) {
                     const int oQ = (r < N - 1) ? p.so.Q : p.so.P;
@@ -332,7 +343,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
                         for (int c = 0; c < NX; ++c) t = __builtin_fma(sh[oQ + a * NX + c], -sh[p.so.xref + c * N + r], t);
 #pragma unroll
-                        for (int c = 0; c < NX; ++c) t = __builtin_fma(A[c][a], lam[c], t);
+                        for (int c = 0; c < NX; ++c) t = __builtin_fma(A2[c][a], lam[c], t);
                         l2[a] = t;
                     }
 #pragma unroll
@@ -345,7 +356,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                         for (int k = 0; k < NU; ++k) {
                             double tk = 0.0;
 #pragma unroll
-                            for (int a = 0; a < NX; ++a) tk = __builtin_fma(Bm[a][k], lam[a], tk);
+                            for (int a = 0; a < NX; ++a) tk = __builtin_fma(B2[a][k], lam[a], tk);
 #pragma unroll
                             for (int j = 0; j < NU; ++j) tk = __builtin_fma(-sh[p.so.R + k * NU + j], sh[p.so.uref + j * N + r], tk);
                             t = (ui == k) ? tk : t;
