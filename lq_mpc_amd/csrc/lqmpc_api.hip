@@ -289,6 +289,8 @@ __global__ void lqmpc_iota_kernel(int *idx, int n)
 
 // Difficulty ordering (options.order): probe launch -> key per instance -> radix sort, hardest first.
 // On success p.perm points at the permutation (slot -> instance).
+// The order only has to group similar instances: the probe stores the upper 32 bits of its (positive) fp64 key,
+// which order like the key itself to 2^-20 relative, and the radix sort runs over half the bits.
 static int build_order(lqmpc_handle *h, KParams &p)
 {
     const size_t B = (size_t)p.Bsz;
@@ -301,8 +303,8 @@ static int build_order(lqmpc_handle *h, KParams &p)
     if (!rc) rc = ensure(h, h->rec, B * rec_doubles * sizeof(double));
     if (rc) return rc;
     size_t tmp_bytes = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, (const double *)h->key.p, (double *)h->key_sorted.p,
-                                                         (const int *)h->idx.p, (int *)h->perm.p, (int)B, 0, 64, h->stream));
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, (const unsigned *)h->key.p, (unsigned *)h->key_sorted.p,
+                                                         (const int *)h->idx.p, (int *)h->perm.p, (int)B, 0, 32, h->stream));
     rc = ensure(h, h->cub_tmp, tmp_bytes);
     if (rc) return rc;
     KParams q = p;
@@ -313,8 +315,8 @@ static int build_order(lqmpc_handle *h, KParams &p)
     const char *name = nullptr;
     if (!lqmpc::launch_spec(q, h->stream, &name)) return fail(LQMPC_ERR_UNSUPPORTED, "probe launch failed");
     hipLaunchKernelGGL(lqmpc_iota_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, (int *)h->idx.p, (int)B);
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(h->cub_tmp.p, tmp_bytes, (const double *)h->key.p, (double *)h->key_sorted.p,
-                                                         (const int *)h->idx.p, (int *)h->perm.p, (int)B, 0, 64, h->stream));
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(h->cub_tmp.p, tmp_bytes, (const unsigned *)h->key.p, (unsigned *)h->key_sorted.p,
+                                                         (const int *)h->idx.p, (int *)h->perm.p, (int)B, 0, 32, h->stream));
     p.perm = (const int *)h->perm.p;
     p.rec = (const double *)h->rec.p;
     return 0;

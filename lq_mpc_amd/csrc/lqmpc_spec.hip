@@ -1219,7 +1219,8 @@ __global__ void __launch_bounds__(64) lqmpc_probe_kernel(KParams p)
             key = fmax(key, fabs(g) * dinv[k]);
         }
     }
-    p.key[b] = (key == key) ? key : 1e300;
+    const double kk = (key == key) ? key : 1e300;
+    ((unsigned *)p.key)[b] = (unsigned)__double2hiint(kk);       // upper half: same order for positive values
 }
 
 // ---------------- registry of built specialisations ----------------
