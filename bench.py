@@ -162,11 +162,13 @@ def main():
     tflops = flops_launch / (kernel_ms * 1e-3) / 1e12
     gbs = bytes_launch / (kernel_ms * 1e-3) / 1e9
     traffic = None
+    mfma_insts = None
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tf):
         try:
             rec = json.load(open(tf)).get(f"{kernel_name}:{args.mode}:C{args.config}:Bsz{Bsz}:T{T}")
             traffic = rec["hbm_bytes_per_launch"] if rec else None
+            mfma_insts = rec.get("mfma_f64_insts_per_launch") if rec else None
         except Exception:
             traffic = None
     roofline = {
@@ -182,6 +184,9 @@ def main():
                 "(interior-point + active-set iterations; 0 for steps the presolve finishes)",
     }
 
+    if mfma_insts:      # the share of the arithmetic that runs on the matrix cores (instruction count from the committed profile)
+        roofline["mfma"] = {"achieved": round(mfma_insts * 2048 / (kernel_ms * 1e-3) / 1e12, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "insts_per_launch": mfma_insts}
     extra = {}
     if args.mode == "rollout" and not args.no_oneshot:
         dt1, kms1, v1 = run(launch_oneshot, max(args.steps, 20), 3, Bsz)

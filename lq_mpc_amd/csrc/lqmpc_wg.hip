@@ -810,14 +810,11 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
 bool launch_wg(const KParams &p, hipStream_t stream, const char **name)
 {
     const size_t bytes = wg_lds_bytes(p.nx, p.nu, p.N);
-    static size_t attr_bytes = 0;            // dynamic-LDS opt-in, raised when a call needs more
-    if (bytes > attr_bytes) {
-        const hipError_t e = hipFuncSetAttribute((const void *)lqmpc_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) {
-            fprintf(stderr, "lqmpc: hipFuncSetAttribute(%zu bytes of LDS): %s\n", bytes, hipGetErrorString(e));
-            return false;
-        }
-        attr_bytes = bytes;
+    // dynamic-LDS opt-in (per device and per function: set on every launch, it is a cheap host-side call)
+    const hipError_t e = hipFuncSetAttribute((const void *)lqmpc_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        fprintf(stderr, "lqmpc: hipFuncSetAttribute(%zu bytes of LDS): %s\n", bytes, hipGetErrorString(e));
+        return false;
     }
 #ifdef LQMPC_WG_PROF
     long long z[16] = {0};
