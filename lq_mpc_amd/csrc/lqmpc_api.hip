@@ -386,11 +386,14 @@ int lqmpc_rollout_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
     if (true_per_instance) { p.At = A_true; p.Bt = B_true; }
     const bool spec = use_spec(h, nx, nu, N);
     const int order = h->opt.order < 0 ? ((spec && p.presolve && T >= 4 && Bsz >= 1024) ? 1 : 0) : (spec ? h->opt.order : 0);
-    // The 16-lane-row kernel on the whole batch is a development switch (LQMPC_R16=1); by default it serves as the
-    // wide tier of the tiered launch below, which is faster.
+    // Which layout (measured at C3 / C2 shapes): up to 16 384 instances the packed kernel does not
+    // fill the GPU (16 or 32 instances per wavefront) and the 16-lane-row kernel takes the whole batch; above that the
+    // sorted batch runs in two tiers, the 16-lane-row layout for its hardest 4 096 instances.  LQMPC_R16=0/1 forces
+    // the choice (development switch).
     const char *r16env = getenv("LQMPC_R16");
-    const bool r16 = spec && h->opt.kernel == LQMPC_KERNEL_AUTO && p.presolve && p.warm_start && lqmpc::r16_available(nx, nu, N) &&
-                     (r16env && r16env[0] == '1') && Bsz <= INT32_MAX;
+    const bool r16ok = spec && h->opt.kernel == LQMPC_KERNEL_AUTO && p.presolve && p.warm_start && lqmpc::r16_available(nx, nu, N) &&
+                       Bsz <= INT32_MAX;
+    const bool r16 = r16ok && (r16env ? r16env[0] == '1' : Bsz <= 16384);
     if (r16) {
         const int r16_order = h->opt.order < 0 ? ((T >= 4 && Bsz >= 1024) ? 1 : 0) : h->opt.order;
         if (r16_order) {
@@ -420,7 +423,7 @@ int lqmpc_rollout_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
         // the hardest instances (first in the order) in the 16-lane-row layout: see lqmpc_spec_tiered_kernel
         if (lqmpc::spec_tiered_available(nx, nu, N) && p.presolve && p.warm_start && Bsz <= INT32_MAX) {
             const char *env = getenv("LQMPC_NWIDE");          // tuning knob for experiments
-            long long nw = env ? atoll(env) : (Bsz / 32) / 4 * 4;   // measured optimum at C3: 2048 .. 4096 of 65536
+            long long nw = env ? atoll(env) : (Bsz / 8 < 4096 ? Bsz / 8 : 4096) / 4 * 4;   // measured: ~one 16-lane-row wave per SIMD
             p.nwide = nw < 0 ? 0 : (nw > Bsz ? Bsz : nw);
         }
         if (p.nwide > 0) {

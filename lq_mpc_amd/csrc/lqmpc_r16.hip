@@ -53,6 +53,7 @@ static void launch_r16_one(const KParams &p, hipStream_t stream)
 #define R16E(NX, NU, N) {NX, NU, N, "lqmpc_r16_kernel<" #NX "," #NU "," #N ">", launch_r16_one<NX, NU, N>}
 static const R16Entry g_r16[] = {
     R16E(4, 2, 10),     // C3 (headline)
+    R16E(2, 1, 10),     // C2
 };
 
 static const R16Entry *find_r16(int nx, int nu, int N)

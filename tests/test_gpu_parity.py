@@ -324,7 +324,8 @@ def test_random_problems(solver, nx, nu, N, warm):
         solver.set_options(warm_start=warm, presolve=warm)
         g1 = solver.solve_batch(N, A, B, Q, R, P, lb, ub, x0, xr, ur)
         g2 = solver.rollout_batch(T, N, A, B, Q, R, P, lb, ub, x0, At, Bt, xr, ur, want_traj=True)
-        assert ("spec" in solver.last_kernel()) == ((nx, nu, N) in [(4, 2, 10), (2, 1, 10), (2, 1, 5), (4, 2, 20)])
+        k = solver.last_kernel()                                  # packed or 16-lane-row specialisation (small batches, warm start on)
+        assert ("spec" in k or "r16" in k) == ((nx, nu, N) in [(4, 2, 10), (2, 1, 10), (2, 1, 5), (4, 2, 20)])
         assert ("wg" in solver.last_kernel()) == wg
     finally:
         solver.set_options(warm_start=-1, presolve=-1)
@@ -382,10 +383,11 @@ def test_workgroup_kernel_dispatch_and_agreement(solver):
         solver.set_options(kernel=KERNEL_AUTO)
 
 
-def test_tiered_rollout_wide_tier_and_hand_back(solver, monkeypatch):
-    """Sorted rollouts run their hardest instances in the 16-lane-row layout (lqmpc_r16_body.h).  References,
-    an off-centre box and per-instance plants go through it; with its iteration cap forced to 1 it hands the
-    constrained instances back (status 3 internally) and the packed kernel's second pass must restore every one."""
+def test_16_lane_row_layout_whole_batch_tiered_and_hand_back(solver, monkeypatch):
+    """Rollouts of up to 16 384 instances run entirely in the 16-lane-row layout (lqmpc_r16_body.h), larger sorted ones
+    use it for their hardest instances (forced here with LQMPC_R16=0 + LQMPC_NWIDE).  References, an off-centre box and
+    per-instance plants go through it; with its iteration cap forced to 1 it hands the constrained instances back
+    (status 3 internally) and the packed kernel's second pass must restore every one."""
     rng = np.random.default_rng(7)
     nx, nu, N, Bsz, T = 4, 2, 10, 2048, 12
     b = synth.make_batch(3, Bsz=Bsz)
@@ -397,12 +399,13 @@ def test_tiered_rollout_wide_tier_and_hand_back(solver, monkeypatch):
     ref = orc.rollout_batch(T, *a, b["x0"], At, Bt, xr, ur, want_traj=True)
     try:
         solver.set_options(order=1)
-        for cap, nwide in ((None, "1024"), ("1", "1024"), (None, "2048")):
-            if cap is None: monkeypatch.delenv("LQMPC_R16_MAXIT", raising=False)
-            else: monkeypatch.setenv("LQMPC_R16_MAXIT", cap)
-            monkeypatch.setenv("LQMPC_NWIDE", nwide)
+        for layout, cap, nwide, name in ((None, None, None, "r16"), (None, "1", None, "r16"), ("0", None, "1024", "tiered"),
+                                         ("0", "1", "1024", "tiered"), ("0", None, "2048", "tiered")):
+            for key, val in (("LQMPC_R16", layout), ("LQMPC_R16_MAXIT", cap), ("LQMPC_NWIDE", nwide)):
+                if val is None: monkeypatch.delenv(key, raising=False)
+                else: monkeypatch.setenv(key, val)
             g = solver.rollout_batch(T, *a, b["x0"], At, Bt, xr, ur, want_traj=True)
-            assert "tiered" in solver.last_kernel()
+            assert name in solver.last_kernel()
             assert np.all(g["status"] == 0)
             assert rel(g["J_T"], ref["J_T"]) < TIGHT and u_err(g["U"], ref["U"]) < RTOL and np.abs(g["X"] - ref["X"]).max() < 1e-7
     finally:
