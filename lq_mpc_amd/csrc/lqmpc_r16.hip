@@ -54,6 +54,8 @@ static void launch_r16_one(const KParams &p, hipStream_t stream)
 static const R16Entry g_r16[] = {
     R16E(4, 2, 10),     // C3 (headline)
     R16E(2, 1, 10),     // C2
+    R16E(2, 1, 5), R16E(2, 1, 6), R16E(2, 1, 7), R16E(2, 1, 8), R16E(2, 1, 9),   // C1 and the reference's horizon sweep
+    R16E(2, 1, 20), R16E(2, 1, 30),   // mpc_test.py (N_open = 20), V_expert (N_opc = 30)
 };
 
 static const R16Entry *find_r16(int nx, int nu, int N)
