@@ -337,6 +337,38 @@ static int launch(lqmpc_handle *h, const KParams &p)
     return 0;
 }
 
+// Which layout (measured at C3 / C2 shapes): up to 16 384 instances the packed kernel does not
+// fill the GPU (16 or 32 instances per wavefront) and the 16-lane-row kernel takes the whole batch; above that sorted
+// rollouts run in two tiers, the 16-lane-row layout for their hardest 4 096 instances.  LQMPC_R16=0/1 forces the
+// choice (development switch).
+static bool use_r16(const lqmpc_handle *h, const KParams &p, int64_t Bsz, int64_t limit = 16384)
+{
+    const char *env = getenv("LQMPC_R16");
+    const bool ok = h->opt.kernel == LQMPC_KERNEL_AUTO && p.presolve && p.warm_start && lqmpc::r16_available(p.nx, p.nu, p.N) &&
+                    Bsz <= INT32_MAX;
+    return ok && (env ? env[0] == '1' : Bsz <= limit);
+}
+
+// 16-lane-row kernel on the whole batch, then the packed kernel over whatever it handed back (device-side list)
+static int launch_r16_with_hand_back(lqmpc_handle *h, KParams &p)
+{
+    int rc = ensure(h, h->fail, ((size_t)p.Bsz + 2) * sizeof(int));
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(h->fail.p, 0, 2 * sizeof(int), h->stream));
+    p.fail_count = (int *)h->fail.p;
+    p.fail_list = (int *)h->fail.p + 2;
+    const char *name = nullptr;
+    if (!lqmpc::launch_r16(p, h->stream, &name)) return fail(LQMPC_ERR_UNSUPPORTED, "r16 launch failed");
+    HIP_TRY(hipGetLastError());
+    KParams f = p;
+    f.perm = p.fail_list; f.count_dev = p.fail_count; f.fail_list = nullptr; f.fail_count = nullptr; f.nwide = 0;
+    const char *name2 = nullptr;
+    if (!lqmpc::launch_spec(f, h->stream, &name2)) return fail(LQMPC_ERR_UNSUPPORTED, "hand-back launch failed");
+    HIP_TRY(hipGetLastError());
+    h->last_kernel = name;
+    return 0;
+}
+
 extern "C" {
 
 int lqmpc_reserve(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int T)
@@ -366,6 +398,7 @@ int lqmpc_solve_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, c
     int rc = prepare(h, c, p);
     if (rc) return rc;
     p.A = dA; p.B = dB; p.x0 = dx0; p.u0 = du0; p.VN = dVN; p.status = dstatus; p.iters = diters;
+    if (use_spec(h, nx, nu, N) && use_r16(h, p, Bsz, 8192)) return launch_r16_with_hand_back(h, p);   // one-shot: setup-bound, crossover earlier
     return launch(h, p);
 }
 
@@ -386,36 +419,13 @@ int lqmpc_rollout_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
     if (true_per_instance) { p.At = A_true; p.Bt = B_true; }
     const bool spec = use_spec(h, nx, nu, N);
     const int order = h->opt.order < 0 ? ((spec && p.presolve && T >= 4 && Bsz >= 1024) ? 1 : 0) : (spec ? h->opt.order : 0);
-    // Which layout (measured at C3 / C2 shapes): up to 16 384 instances the packed kernel does not
-    // fill the GPU (16 or 32 instances per wavefront) and the 16-lane-row kernel takes the whole batch; above that the
-    // sorted batch runs in two tiers, the 16-lane-row layout for its hardest 4 096 instances.  LQMPC_R16=0/1 forces
-    // the choice (development switch).
-    const char *r16env = getenv("LQMPC_R16");
-    const bool r16ok = spec && h->opt.kernel == LQMPC_KERNEL_AUTO && p.presolve && p.warm_start && lqmpc::r16_available(nx, nu, N) &&
-                       Bsz <= INT32_MAX;
-    const bool r16 = r16ok && (r16env ? r16env[0] == '1' : Bsz <= 16384);
-    if (r16) {
+    if (spec && use_r16(h, p, Bsz)) {
         const int r16_order = h->opt.order < 0 ? ((T >= 4 && Bsz >= 1024) ? 1 : 0) : h->opt.order;
         if (r16_order) {
             rc = build_order(h, p);
             if (rc) return rc;
         }
-        rc = ensure(h, h->fail, ((size_t)Bsz + 2) * sizeof(int));
-        if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(h->fail.p, 0, 2 * sizeof(int), h->stream));
-        p.fail_count = (int *)h->fail.p;
-        p.fail_list = (int *)h->fail.p + 2;
-        const char *name = nullptr;
-        if (!lqmpc::launch_r16(p, h->stream, &name)) return fail(LQMPC_ERR_UNSUPPORTED, "r16 launch failed");
-        HIP_TRY(hipGetLastError());
-        // second pass: whatever the first one handed back, on the packed kernel, from the start of the rollout
-        KParams f = p;
-        f.perm = p.fail_list; f.count_dev = p.fail_count; f.fail_list = nullptr; f.fail_count = nullptr; f.nwide = 0;
-        const char *name2 = nullptr;
-        if (!lqmpc::launch_spec(f, h->stream, &name2)) return fail(LQMPC_ERR_UNSUPPORTED, "fallback launch failed");
-        HIP_TRY(hipGetLastError());
-        h->last_kernel = name;
-        return 0;
+        return launch_r16_with_hand_back(h, p);
     }
     if (order) {
         rc = build_order(h, p);
@@ -458,6 +468,7 @@ int lqmpc_max_vn_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, 
     int rc = prepare(h, c, p);
     if (rc) return rc;
     p.A = dA; p.B = dB; p.MV = dMV; p.status = dstatus; p.iters = diters;
+    if (use_spec(h, nx, nu, N) && use_r16(h, p, Bsz, 8192)) return launch_r16_with_hand_back(h, p);   // one-shot: setup-bound, crossover earlier
     return launch(h, p);
 }
 

@@ -21,11 +21,11 @@
 
 namespace lqmpc {
 
-template <int NX, int NU, int N>
+template <int NX, int NU, int N, int MODE>
 __global__ void __launch_bounds__(64, 1) lqmpc_r16_kernel(KParams p)
 {
     __shared__ double lds_raw[4 * R16<NX, NU, N>::INST];
-    r16_body<NX, NU, N>(p, lds_raw, (long long)blockIdx.x * 4, p.Bsz);
+    r16_body<NX, NU, N, MODE>(p, lds_raw, (long long)blockIdx.x * 4, p.Bsz);
 }
 
 struct R16Entry {
@@ -37,17 +37,22 @@ struct R16Entry {
 template <int NX, int NU, int N>
 static void launch_r16_one(const KParams &p, hipStream_t stream)
 {
+    const dim3 grid((unsigned)((p.Bsz + 3) / 4));
+    if (p.mode == MODE_SOLVE) hipLaunchKernelGGL((lqmpc_r16_kernel<NX, NU, N, MODE_SOLVE>), grid, dim3(64), 0, stream, p);
+    else if (p.mode == MODE_MAXVN) hipLaunchKernelGGL((lqmpc_r16_kernel<NX, NU, N, MODE_MAXVN>), grid, dim3(64), 0, stream, p);
+    else {
 #ifdef LQMPC_R16_PROF
-    long long z[16] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_r16_prof), z, sizeof z);
+        long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_r16_prof), z, sizeof z);
 #endif
-    hipLaunchKernelGGL((lqmpc_r16_kernel<NX, NU, N>), dim3((unsigned)((p.Bsz + 3) / 4)), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((lqmpc_r16_kernel<NX, NU, N, MODE_ROLLOUT>), grid, dim3(64), 0, stream, p);
 #ifdef LQMPC_R16_PROF
-    (void)hipStreamSynchronize(stream);
-    (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_r16_prof), sizeof z);
-    fprintf(stderr, "r16 prof (block %d ticks): chains %lld images+T %lld suffix/P %lld Fq %lld qr %lld invert %lld G/store %lld | rollout %lld\n",
-            PROFBLK, z[0], z[1], z[2], z[3], z[4], z[5], z[6], z[7]);
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_r16_prof), sizeof z);
+        fprintf(stderr, "r16 prof (block %d ticks): chains %lld images+T %lld suffix/P %lld Fq %lld qr %lld invert %lld G/store %lld | rollout %lld\n",
+                PROFBLK, z[0], z[1], z[2], z[3], z[4], z[5], z[6], z[7]);
 #endif
+    }
 }
 
 #define R16E(NX, NU, N) {NX, NU, N, "lqmpc_r16_kernel<" #NX "," #NU "," #N ">", launch_r16_one<NX, NU, N>}

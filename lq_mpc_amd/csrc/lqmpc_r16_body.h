@@ -84,7 +84,7 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make
 __device__ __forceinline__ unsigned ballot16(bool c, int q) { return (unsigned)((__ballot(c) >> (16 * q)) & 0xFFFFull); }
 
 // One wavefront's work: the four instances in slots slot0 .. slot0 + 3 (slots >= slot_end are surplus).
-template <int NX, int NU, int N>
+template <int NX, int NU, int N, int MODE>
 __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long long slot0, long long slot_end)
 {
     using C = R16<NX, NU, N>;
@@ -419,40 +419,23 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     }
     RPROF_START;
 
-    // ---------------- closed loop (utils_class.py:266-283) ----------------
-    double x[NX];
+    // ---------------- the requested operation ----------------
+    // stage weights once: inside the step loop they would be vector loads per step
+    double Qm[NX][NX], Rm[NU][NU];
 #pragma unroll
-    for (int a = 0; a < NX; ++a) x[a] = p.rec ? p.rec[b * REC + NX * NX + NX * NU + a] : p.x0[(long long)a * Bsz + b];
-    // stage weights and the plant once: inside the step loop they would be 22 vector loads per step
-    double Qm[NX][NX], Rm[NU][NU], Atm[NX][NX], Btm[NX][NU];
+    for (int a = 0; a < NX; ++a)
 #pragma unroll
-    for (int a = 0; a < NX; ++a) {
-#pragma unroll
-        for (int c = 0; c < NX; ++c) {
-            Qm[a][c] = sh[p.so.Q + a * NX + c];
-            Atm[a][c] = p.true_per_instance ? p.At[(long long)(a * NX + c) * Bsz + b] : sh[p.so.At + a * NX + c];
-        }
-#pragma unroll
-        for (int k = 0; k < NU; ++k) Btm[a][k] = p.true_per_instance ? p.Bt[(long long)(a * NU + k) * Bsz + b] : sh[p.so.Bt + a * NU + k];
-    }
+        for (int c = 0; c < NX; ++c) Qm[a][c] = sh[p.so.Q + a * NX + c];
 #pragma unroll
     for (int k = 0; k < NU; ++k)
 #pragma unroll
         for (int j = 0; j < NU; ++j) Rm[k][j] = sh[p.so.R + k * NU + j];
-    double cost = 0.0;
-#pragma unroll
-    for (int a = 0; a < NX; ++a)
-#pragma unroll
-        for (int c = 0; c < NX; ++c) cost = __builtin_fma(x[a] * Qm[a][c], x[c], cost);
     const bool writer = valid && i == 0;
-    if (p.X && writer) {
-#pragma unroll
-        for (int a = 0; a < NX; ++a) p.X[((long long)a * (p.T + 1)) * Bsz + b] = x[a];
-    }
     unsigned pL = 0, pU = 0;                  // active set of the previous step (row-uniform bit masks)
     int iters = 0, status = 0;
-    for (int t = 0; t < p.T; ++t) {
-        double vu[RB], v[RB];
+    // ---- one box QP at state x: v <- the optimum (my rows); updates the warm-start face, iters, status ----
+    auto qp = [&](const double (&x)[NX], double (&v)[RB]) {
+        double vu[RB];
         unsigned cl = 0, cu = 0;
         bool bad = false;
 #pragma unroll
@@ -599,46 +582,150 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         } else {
             pL = mL; pU = mU;
         }
-        // u_k = clipped v of row k + centre, from lane k of the row
-        double u[NU], xn[NX];
+    };
+    // u_k of stage st after a solve: clipped v of row st*NU + k plus the centre, from the lane that holds the row
+    auto stage_input = [&](const double (&v)[RB], int st, double (&u)[NU]) {
 #pragma unroll
         for (int k = 0; k < NU; ++k) {
-            const double uk = fmin(fmax(v[k / 16], -h[k / 16]), h[k / 16]) + ctr[k / 16];
-            u[k] = rowb(uk, k % 16);
+            const int row = st * NU + k;                         // compile-time after unrolling
+            const double uk = fmin(fmax(v[row / 16], -h[row / 16]), h[row / 16]) + ctr[row / 16];
+            u[k] = rowb(uk, row % 16);
         }
+    };
+    if (MODE == MODE_ROLLOUT) {
+        // closed loop (utils_class.py:266-283)
+        double x[NX], Atm[NX][NX], Btm[NX][NU];
 #pragma unroll
         for (int a = 0; a < NX; ++a) {
-            double acc = 0.0;
+            x[a] = p.rec ? p.rec[b * REC + NX * NX + NX * NU + a] : p.x0[(long long)a * Bsz + b];
 #pragma unroll
-            for (int c = 0; c < NX; ++c) acc = __builtin_fma(Atm[a][c], x[c], acc);
+            for (int c = 0; c < NX; ++c) Atm[a][c] = p.true_per_instance ? p.At[(long long)(a * NX + c) * Bsz + b] : sh[p.so.At + a * NX + c];
 #pragma unroll
-            for (int k = 0; k < NU; ++k) acc = __builtin_fma(Btm[a][k], u[k], acc);
-            xn[a] = acc;
+            for (int k = 0; k < NU; ++k) Btm[a][k] = p.true_per_instance ? p.Bt[(long long)(a * NU + k) * Bsz + b] : sh[p.so.Bt + a * NU + k];
         }
-#pragma unroll
-        for (int a = 0; a < NX; ++a) x[a] = xn[a];
+        double cost = 0.0;
 #pragma unroll
         for (int a = 0; a < NX; ++a)
 #pragma unroll
-            for (int c = 0; c < NX; ++c) cost = __builtin_fma(xn[a] * Qm[a][c], xn[c], cost);
+            for (int c = 0; c < NX; ++c) cost = __builtin_fma(x[a] * Qm[a][c], x[c], cost);
+        if (p.X && writer) {
 #pragma unroll
-        for (int k = 0; k < NU; ++k)
+            for (int a = 0; a < NX; ++a) p.X[((long long)a * (p.T + 1)) * Bsz + b] = x[a];
+        }
+        for (int t = 0; t < p.T; ++t) {
+            double v[RB], u[NU], xn[NX];
+            qp(x, v);
+            stage_input(v, 0, u);
 #pragma unroll
-            for (int j = 0; j < NU; ++j) cost = __builtin_fma(u[k] * Rm[k][j], u[j], cost);
-        if (writer) {
-            if (p.X) {
+            for (int a = 0; a < NX; ++a) {
+                double acc = 0.0;
 #pragma unroll
-                for (int a = 0; a < NX; ++a) p.X[((long long)a * (p.T + 1) + t + 1) * Bsz + b] = xn[a];
+                for (int c = 0; c < NX; ++c) acc = __builtin_fma(Atm[a][c], x[c], acc);
+#pragma unroll
+                for (int k = 0; k < NU; ++k) acc = __builtin_fma(Btm[a][k], u[k], acc);
+                xn[a] = acc;
             }
-            if (p.U) {
 #pragma unroll
-                for (int k = 0; k < NU; ++k) p.U[((long long)k * p.T + t) * Bsz + b] = u[k];
+            for (int a = 0; a < NX; ++a) x[a] = xn[a];
+#pragma unroll
+            for (int a = 0; a < NX; ++a)
+#pragma unroll
+                for (int c = 0; c < NX; ++c) cost = __builtin_fma(xn[a] * Qm[a][c], xn[c], cost);
+#pragma unroll
+            for (int k = 0; k < NU; ++k)
+#pragma unroll
+                for (int j = 0; j < NU; ++j) cost = __builtin_fma(u[k] * Rm[k][j], u[j], cost);
+            if (writer) {
+                if (p.X) {
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) p.X[((long long)a * (p.T + 1) + t + 1) * Bsz + b] = xn[a];
+                }
+                if (p.U) {
+#pragma unroll
+                    for (int k = 0; k < NU; ++k) p.U[((long long)k * p.T + t) * Bsz + b] = u[k];
+                }
             }
         }
+        RPROF(7);
+        if (writer) p.JT[b] = cost;
+    } else {
+        // open loop (utils_class.py:48-91): V_N by rolling the MODEL forward with the optimal inputs
+        double Am[NX][NX], Bmm[NX][NU], Pm[NX][NX];
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+#pragma unroll
+            for (int c = 0; c < NX; ++c) {
+                Am[a][c] = p.rec ? p.rec[b * REC + a * NX + c] : p.A[(long long)(a * NX + c) * Bsz + b];
+                Pm[a][c] = sh[p.so.P + a * NX + c];
+            }
+#pragma unroll
+            for (int k = 0; k < NU; ++k) Bmm[a][k] = p.rec ? p.rec[b * REC + NX * NX + a * NU + k] : p.B[(long long)(a * NU + k) * Bsz + b];
+        }
+        auto value_fn = [&](const double (&x0v)[NX], const double (&v)[RB]) -> double {
+            double xs[NX], c = 0.0;
+#pragma unroll
+            for (int a = 0; a < NX; ++a) xs[a] = x0v[a];
+#pragma unroll
+            for (int a = 0; a < NX; ++a)
+#pragma unroll
+                for (int cc = 0; cc < NX; ++cc) c = __builtin_fma(xs[a] * Qm[a][cc], xs[cc], c);
+            static_for<N>([&](auto kc) {
+                constexpr int st = decltype(kc)::value;
+                double u[NU], xn[NX];
+                stage_input(v, st, u);
+#pragma unroll
+                for (int a = 0; a < NX; ++a) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int cc = 0; cc < NX; ++cc) acc = __builtin_fma(Am[a][cc], xs[cc], acc);
+#pragma unroll
+                    for (int k = 0; k < NU; ++k) acc = __builtin_fma(Bmm[a][k], u[k], acc);
+                    xn[a] = acc;
+                }
+#pragma unroll
+                for (int a = 0; a < NX; ++a) { xs[a] = xn[a]; if (p.has_ref) xn[a] -= sh[p.so.xref + a * N + st]; }
+#pragma unroll
+                for (int a = 0; a < NX; ++a)
+#pragma unroll
+                    for (int cc = 0; cc < NX; ++cc) c = __builtin_fma(xn[a] * ((st == N - 1) ? Pm[a][cc] : Qm[a][cc]), xn[cc], c);
+                if (p.has_ref) {
+#pragma unroll
+                    for (int k = 0; k < NU; ++k) u[k] -= sh[p.so.uref + k * N + st];
+                }
+#pragma unroll
+                for (int k = 0; k < NU; ++k)
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) c = __builtin_fma(u[k] * Rm[k][j], u[j], c);
+            });
+            return c;
+        };
+        if (MODE == MODE_SOLVE) {
+            double x[NX], v[RB], u[NU];
+#pragma unroll
+            for (int a = 0; a < NX; ++a) x[a] = p.rec ? p.rec[b * REC + NX * NX + NX * NU + a] : p.x0[(long long)a * Bsz + b];
+            qp(x, v);
+            const double vn = value_fn(x, v);
+            stage_input(v, 0, u);
+            if (writer) {
+                p.VN[b] = vn;
+#pragma unroll
+                for (int k = 0; k < NU; ++k) p.u0[(long long)k * Bsz + b] = u[k];
+            }
+        } else {
+            double best = -1e308;
+            for (int kk = 0; kk < p.K; ++kk) {
+                double x[NX], v[RB];
+#pragma unroll
+                for (int a = 0; a < NX; ++a) x[a] = sh[p.so.x0s + a * p.K + kk];
+                pL = 0; pU = 0;
+                qp(x, v);
+                const double vn = value_fn(x, v);
+                best = (vn > best || vn != vn) ? vn : best;
+            }
+            if (writer) p.MV[b] = best;
+        }
     }
-    RPROF(7);
     if (writer) {
-        p.JT[b] = cost;
         if (p.status) p.status[b] = status;
         if (p.iters) p.iters[b] = iters;
         if (status == 3 && p.fail_list) p.fail_list[atomicAdd(p.fail_count, 1)] = (int)b;

@@ -1142,7 +1142,7 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_tiered_kernel(KParams p)
     constexpr int LDSZ = R16SZ > SP::LDS_DOUBLES ? R16SZ : SP::LDS_DOUBLES;
     __shared__ double lds[LDSZ];
     const long long blk = blockIdx.x, nb16 = (p.nwide + 3) / 4;
-    if (blk < nb16) r16_body<NX, NU, N>(p, lds, blk * 4, p.nwide);
+    if (blk < nb16) r16_body<NX, NU, N, MODE>(p, lds, blk * 4, p.nwide);
     else spec_body<NX, NU, N, LPS, MODE>(p, lds, p.nwide + (blk - nb16) * SP::SPW, p.Bsz);
 }
 
