@@ -1,22 +1,26 @@
-// lqmpc_r16.hip -- closed-loop rollouts for n = N*nu <= 32: one instance per 16-lane row of a wavefront (four
-// per wave), matrix row i of an instance in lane i % 16 (slot i / 16).
+// lqmpc_r16.hip -- solve / rollout / max-V_N for n = N*nu <= 32 with one instance per 16-lane row of a wavefront
+// (four per wave), matrix row i of an instance in lane i % 16 (slot i / 16).  Device code: lqmpc_r16_body.h.
 //
 // Why another layout.  The packed register-resident kernel (lqmpc_spec.hip) factors the masked n x n matrix in
-// every active-set iteration: ~4000 instructions per iteration and wave, one wave per SIMD (512 registers, 40
-// KiB of LDS), so the launch lasts as long as the wave holding the instances that stay constrained for all T
-// steps (C3: 78 iterations, 1.1 ms).  Here an iteration costs a few hundred instructions because it only ever
-// solves the SMALLER side of the active-set system:
+// every active-set iteration: ~4000 instructions per iteration and wave of 16 instances, one wave per SIMD (512
+// registers, 40 KiB of LDS), so a sorted launch lasts as long as the wave holding the instances that stay
+// constrained for all T steps (C3: 78 iterations, 1.1 ms), and a batch below ~16 000 instances leaves most SIMDs
+// idle.  Here an iteration costs ~1000 instructions per wave of 4 instances because it only ever solves the
+// SMALLER side of the active-set system:
 //   with A the active set (signs s), F the free set, r_A = v_unc,A - s h_A and W = P^-1,
 //     |A| <= |F| (dual side):    W_AA lam = r_A,          v_F = v_unc,F - W_FA lam,          gradient on A = -lam
 //     |A| >  |F| (primal side):  P_FF dlt = P_FA r_A,     v_F = v_unc,F + dlt,               gradient on A = P_AF dlt - P_AA r_A
 //   both are the same iterate of the primal-dual active-set method the other kernels use; min(|A|, |F|) <= 16.
-// P and W live packed in LDS (3.4 KB per instance at n = 20), the gathered system is solved in registers by
-// Gauss-Jordan elimination with DPP row broadcasts (v_fmac_f64_dpp row_newbcast: the pivot row reaches the 16
-// lanes of an instance without leaving the vector registers).  W itself comes from P by the same elimination.
-// Register and LDS needs are small enough for two to three waves per SIMD.
+// P and W live in LDS with full rows (7.8 KB per instance at n = 20: every access is row base + constant), the
+// gathered system is solved in registers by Gauss-Jordan elimination with DPP row broadcasts (v_fmac_f64_dpp
+// row_newbcast: the pivot row reaches the 16 lanes of an instance without leaving the vector registers).  W itself
+// comes from P by the same elimination.
 //
-// An instance whose active set does not settle within MAXIT iterations is reported with status 3; the host
-// re-runs exactly those instances on the packed kernel (interior point + active-set finishing).
+// Used for whole batches up to 16 384 instances (rollouts; 8 192 for the one-shot entry points) and as the wide
+// tier of larger sorted rollouts (lqmpc_spec_tiered_kernel); the host picks (lqmpc_api.hip: use_r16).
+// An instance whose active set does not settle within the iteration cap is reported with status 3 internally; the
+// host re-runs exactly those instances on the packed kernel (interior point + active-set finishing) in a second
+// launch over a device-side list.
 #include "lqmpc_r16_body.h"
 
 namespace lqmpc {

@@ -33,8 +33,8 @@ struct R16 {
     static constexpr int LDW = n + 1;                // row stride of P and W: odd, so that a column read is conflict-free
     static constexpr int PK = n * LDW;               // both stored in full: every access below is row base + constant
     static constexpr int VEC = 16 * RB;
-    // LDS per instance, in doubles: P | W | vu | r | x | y | list (16 ints)
-    static constexpr int oP = 0, oW = PK, oVU = 2 * PK, oR = oVU + VEC, oX = oR + VEC, oY = oX + VEC, oL = oY + VEC;
+    // LDS per instance, in doubles: P | W | r | x | y | list (16 ints)
+    static constexpr int oP = 0, oW = PK, oR = 2 * PK, oX = oR + VEC, oY = oX + VEC, oL = oY + VEC;
     static constexpr int SETUP = oW + 3 * n * NX + N * NX * NX;          // condensing tables alias the W region and what follows
     static constexpr int INST = (oL + 8 > SETUP) ? oL + 8 : SETUP;
     static constexpr int MAXIT = 12;
@@ -92,7 +92,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     constexpr int REC = NX * NX + NX * NU + NX;
     const int lane = threadIdx.x, q = lane >> 4, i = lane & 15;
     ldsd *L = (ldsd *)lds_raw + q * C::INST;
-    ldsd *Pp = L + C::oP, *Wp = L + C::oW, *vuL = L + C::oVU, *rL = L + C::oR, *xL = L + C::oX, *yL = L + C::oY;
+    ldsd *Pp = L + C::oP, *Wp = L + C::oW, *rL = L + C::oR, *xL = L + C::oX, *yL = L + C::oY;
     ldsi *list = (ldsi *)(L + C::oL);
     const long long Bsz = p.Bsz;
     const long long b_raw = slot0 + q;
@@ -479,7 +479,6 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 for (int s = 0; s < RB; ++s) {
                     const unsigned bit = 1u << rw[s];
                     const double sg = (mL & bit) ? -1.0 : ((mU & bit) ? 1.0 : 0.0);
-                    vuL[rw[s]] = vu[s];
                     rL[rw[s]] = (sg != 0.0) ? vu[s] - sg * h[s] : 0.0;
                     xL[rw[s]] = 0.0;
                     if (vrow[s] && (mC & bit)) list[__popc(mC & (bit - 1u))] = rw[s];
