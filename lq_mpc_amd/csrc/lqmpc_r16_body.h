@@ -35,8 +35,9 @@ struct R16 {
     static constexpr int VEC = 16 * RB;
     // LDS per instance, in doubles: P | W | r | x | y | list (16 ints)
     static constexpr int oP = 0, oW = PK, oR = 2 * PK, oX = oR + VEC, oY = oX + VEC, oL = oY + VEC;
+    static constexpr int oD = oL + 8;                 // a dummy slot: predicated LDS stores go there instead of toggling exec
     static constexpr int SETUP = oW + 3 * n * NX + N * NX * NX;          // condensing tables alias the W region and what follows
-    static constexpr int INST = (oL + 8 > SETUP) ? oL + 8 : SETUP;
+    static constexpr int INST = (oD + 2 > SETUP) ? oD + 2 : SETUP;
     static constexpr int MAXIT = 12;
     static_assert(n <= 32, "one or two row slots per lane");
 };
@@ -94,6 +95,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     ldsd *L = (ldsd *)lds_raw + q * C::INST;
     ldsd *Pp = L + C::oP, *Wp = L + C::oW, *rL = L + C::oR, *xL = L + C::oX, *yL = L + C::oY;
     ldsi *list = (ldsi *)(L + C::oL);
+    constexpr int DUMMY = C::oD - C::oP, DUMMYW = C::oD - C::oW;     // the dummy slot as an index into P / W
     const long long Bsz = p.Bsz;
     const long long b_raw = slot0 + q;
     const bool valid = b_raw < slot_end;
@@ -184,9 +186,10 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
                         for (int a = 0; a < NX; ++a) ma[s][a] = (mine && rw[s] % NU == k) ? Mc[a][k] : ma[s][a];
                 }
+                if (i == 0) {                                            // one lane stores A^(m+1) (one exec toggle per power)
 #pragma unroll
-                for (int e = 0; e < NX * NX; ++e)
-                    if ((e & 15) == i) AP[m * NX * NX + e] = Ap[e / NX][e % NX];      // AP[m] = A^(m+1)
+                    for (int e = 0; e < NX * NX; ++e) AP[m * NX * NX + e] = Ap[e / NX][e % NX];
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -194,6 +197,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         double pm[RB][NX];
 #pragma unroll
         for (int s = 0; s < RB; ++s) {
+            double qmv[NX];
 #pragma unroll
             for (int a = 0; a < NX; ++a) {
                 double t1 = 0.0, t2 = 0.0;
@@ -202,8 +206,11 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                     t1 = __builtin_fma(sh[p.so.P + a * NX + c], ma[s][c], t1);
                     t2 = __builtin_fma(sh[p.so.Q + a * NX + c], ma[s][c], t2);
                 }
-                pm[s][a] = t1;
-                if (vrow[s]) { MA[rw[s] * NX + a] = ma[s][a]; PM[rw[s] * NX + a] = t1; QM[rw[s] * NX + a] = t2; }
+                pm[s][a] = t1; qmv[a] = t2;
+            }
+            if (vrow[s]) {
+#pragma unroll
+                for (int a = 0; a < NX; ++a) { MA[rw[s] * NX + a] = ma[s][a]; PM[rw[s] * NX + a] = pm[s][a]; QM[rw[s] * NX + a] = qmv[a]; }
             }
         }
         __syncthreads();
@@ -224,7 +231,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
                     for (int a = 0; a < NX; ++a) t = __builtin_fma(man[a], QM[(j + NU) * NX + a] - PM[(j + NU) * NX + a], t);
                 }
-                if (vrow[s] && j <= rw[s]) Pp[rw[s] * LDW + j] = t;
+                Pp[(vrow[s] && j <= rw[s]) ? rw[s] * LDW + j : DUMMY] = t;
                 if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // straight-line code: keep the loads near their use
             }
         }
@@ -259,7 +266,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 if (j > 16 * s + 15) continue;
                 const double val = 2.0 * (Wr[s][j] + ((j / NU == bi) ? sh[p.so.R + ui * NU + (j % NU)] : 0.0));
                 Wr[s][j] = val;
-                if (vrow[s] && j <= rw[s]) Pp[rw[s] * LDW + j] = val;
+                Pp[(vrow[s] && j <= rw[s]) ? rw[s] * LDW + j : DUMMY] = val;
             }
         }
         __syncthreads();
@@ -276,7 +283,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         for (int s = 0; s < RB; ++s)
 #pragma unroll
             for (int j = 0; j < n; ++j)
-                if (vrow[s] && j > rw[s]) Pp[rw[s] * LDW + j] = Wr[s][j];          // the upper triangle: rows are stored in full
+                Pp[(vrow[s] && j > rw[s]) ? rw[s] * LDW + j : DUMMY] = Wr[s][j];   // the upper triangle: rows are stored in full
         RPROF(2);
         __builtin_amdgcn_sched_barrier(0);
         // Fq rows: power by power (d outer), so that each A^(N-d) is fetched once for both row slots
@@ -403,7 +410,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         for (int s = 0; s < RB; ++s) {
 #pragma unroll
             for (int j = 0; j < n; ++j)
-                if (vrow[s]) Wp[rw[s] * LDW + j] = Wr[s][j];
+                Wp[vrow[s] ? rw[s] * LDW + j : DUMMYW] = Wr[s][j];
             if (!vrow[s]) {
                 vr[s] = 0.0;
 #pragma unroll
