@@ -495,12 +495,16 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 const int la = (i < c) ? list[i] : 0;
                 double S[16], rhs;
 #pragma unroll
-                for (int bb = 0; bb < 16; ++bb) {
-                    S[bb] = (bb == i) ? 1.0 : 0.0;
-                    if (bb < cw) {                               // uniform
-                        const int lb = (bb < c) ? list[bb] : 0;
-                        const double val = Mx[la * LDW + lb];
-                        if (i < c && bb < c) S[bb] = val;
+                for (int bg = 0; bg < 4; ++bg) {                 // columns in groups of four: one uniform test per group
+#pragma unroll
+                    for (int bb = 4 * bg; bb < 4 * bg + 4; ++bb) S[bb] = (bb == i) ? 1.0 : 0.0;
+                    if (4 * bg < cw) {
+#pragma unroll
+                        for (int bb = 4 * bg; bb < 4 * bg + 4; ++bb) {
+                            const int lb = (bb < c) ? list[bb] : 0;
+                            const double val = Mx[la * LDW + lb];
+                            if (i < c && bb < c) S[bb] = val;
+                        }
                     }
                 }
                 rhs = (i < c && dual) ? rL[la] : 0.0;
@@ -512,8 +516,8 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 }
                 // Gauss-Jordan on [S | rhs]: afterwards S = I and rhs = the solution
                 bool ok = true;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
+                static_for<16>([&](auto kc) {                    // (compile-time pivot index: the DPP control is an immediate)
+                    constexpr int k = decltype(kc)::value;
                     if (k < cw) {                                // uniform
                         dpp_settle(S[k]);
                         const double d = rowb(S[k], k);
@@ -521,11 +525,16 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                         const double inv = frcp(d);
                         const double g = (i == k) ? (inv - 1.0) : -S[k] * inv;
 #pragma unroll
-                        for (int j = k + 1; j < 16; ++j)
-                            if (j < cw) fmac_rowb_self(S[j], g, k);
+                        for (int jg = 0; jg < 4; ++jg) {         // columns in groups of four: one uniform test per group
+                            if (4 * jg + 3 > k && 4 * jg < cw) {  // first half static, second uniform
+#pragma unroll
+                                for (int j = 4 * jg; j < 4 * jg + 4; ++j)
+                                    if (j > k) fmac_rowb_self(S[j], g, k);
+                            }
+                        }
                         fmac_rowb_self(rhs, g, k);
                     }
-                }
+                });
                 const bool rowfail = ballot16(!ok, q) != 0;
                 if (i < c) xL[la] = rhs;
                 __syncthreads();
