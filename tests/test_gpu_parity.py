@@ -296,7 +296,7 @@ def test_difficulty_ordering_is_transparent(solver, golden_dir):
 WG_SHAPES = [(8, 4, 30), (6, 3, 15), (16, 2, 17), (3, 2, 64), (5, 1, 33)]     # n = 120, 45, 34, 128, 33
 
 
-@pytest.mark.parametrize("nx,nu,N", [(4, 2, 10), (2, 1, 10), (2, 1, 5), (3, 2, 6), (1, 1, 1), (5, 3, 4), (4, 2, 20)] + WG_SHAPES)
+@pytest.mark.parametrize("nx,nu,N", [(4, 2, 10), (2, 1, 10), (2, 1, 5), (2, 1, 7), (2, 1, 20), (2, 1, 30), (3, 2, 6), (1, 1, 1), (5, 3, 4), (4, 2, 20)] + WG_SHAPES)
 @pytest.mark.parametrize("warm", [0, 1])
 def test_random_problems(solver, nx, nu, N, warm):
     """Unstable / badly scaled models, dense Q/R/P, asymmetric boxes, references, per-instance plants, on the
@@ -325,7 +325,7 @@ def test_random_problems(solver, nx, nu, N, warm):
         g1 = solver.solve_batch(N, A, B, Q, R, P, lb, ub, x0, xr, ur)
         g2 = solver.rollout_batch(T, N, A, B, Q, R, P, lb, ub, x0, At, Bt, xr, ur, want_traj=True)
         k = solver.last_kernel()                                  # packed or 16-lane-row specialisation (small batches, warm start on)
-        assert ("spec" in k or "r16" in k) == ((nx, nu, N) in [(4, 2, 10), (2, 1, 10), (2, 1, 5), (4, 2, 20)])
+        assert ("spec" in k or "r16" in k) == ((nx, nu, N) in [(4, 2, 10), (2, 1, 10), (2, 1, 5), (2, 1, 7), (2, 1, 20), (2, 1, 30), (4, 2, 20)])
         assert ("wg" in solver.last_kernel()) == wg
     finally:
         solver.set_options(warm_start=-1, presolve=-1)
