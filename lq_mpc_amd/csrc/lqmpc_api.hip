@@ -281,12 +281,6 @@ static int prepare(lqmpc_handle *h, const Call &c, KParams &p)
     return 0;
 }
 
-__global__ void lqmpc_iota_kernel(int *idx, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) idx[i] = i;
-}
-
 // Difficulty ordering (options.order): probe launch -> key per instance -> radix sort, hardest first.
 // On success p.perm points at the permutation (slot -> instance).
 // The order only has to group similar instances: the probe stores the upper 32 bits of its (positive) fp64 key,
@@ -312,9 +306,9 @@ static int build_order(lqmpc_handle *h, KParams &p)
     q.perm = nullptr;
     q.key = (double *)h->key.p;
     q.stage = (double *)h->rec.p;
+    q.fail_list = (int *)h->idx.p;             // the probe also writes the identity permutation (saves a launch)
     const char *name = nullptr;
     if (!lqmpc::launch_spec(q, h->stream, &name)) return fail(LQMPC_ERR_UNSUPPORTED, "probe launch failed");
-    hipLaunchKernelGGL(lqmpc_iota_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, (int *)h->idx.p, (int)B);
     HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(h->cub_tmp.p, tmp_bytes, (const unsigned *)h->key.p, (unsigned *)h->key_sorted.p,
                                                          (const int *)h->idx.p, (int *)h->perm.p, (int)B, 0, 32, h->stream));
     p.perm = (const int *)h->perm.p;

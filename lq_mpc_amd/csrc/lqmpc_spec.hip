@@ -1221,6 +1221,7 @@ __global__ void __launch_bounds__(64) lqmpc_probe_kernel(KParams p)
     }
     const double kk = (key == key) ? key : 1e300;
     ((unsigned *)p.key)[b] = (unsigned)__double2hiint(kk);       // upper half: same order for positive values
+    if (p.fail_list) p.fail_list[b] = (int)b;                       // the identity permutation the sort starts from (borrowed field)
 }
 
 // ---------------- registry of built specialisations ----------------
