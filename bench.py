@@ -111,6 +111,27 @@ def main():
         s.solve_batch_dev(nx, nu, N, Bsz, dA, dB, b["Q"], b["R"], b["P"], b["lb"], b["ub"], dx0, du0, dVN,
                           dstatus=dst, diters=dit)
 
+    # N > 1: after every step the per-instance cost curve J_T is all-gathered (RCCL).  The collective of step k
+    # runs while the rollout of step k+1 computes: J_T is copied to one of two staging buffers on the launch stream, the
+    # gather is issued asynchronously on it, and it is waited for one step later (and before the timed region closes).
+    gather = {"pending": None, "k": 0}
+    if world > 1:
+        stage_bufs = [torch.empty(Bsz, dtype=torch.float64, device=cdev) for _ in range(2)]
+        out_bufs = [torch.empty(world * Bsz, dtype=torch.float64, device=cdev) for _ in range(2)]
+
+    def gather_costs():
+        k = gather["k"] & 1
+        stage_bufs[k].copy_(dJT)                                  # device-to-device under nccl, device-to-host under gloo
+        if gather["pending"] is not None:
+            gather["pending"].wait()
+        gather["pending"] = dist.all_gather_into_tensor(out_bufs[k], stage_bufs[k], async_op=True)
+        gather["k"] += 1
+
+    def gather_flush():
+        if gather["pending"] is not None:
+            gather["pending"].wait()
+            gather["pending"] = None
+
     def run(launch, steps, warmup, qp_per_launch):
         def one_step(ev=None):
             if ev is not None:
@@ -119,9 +140,11 @@ def main():
             if ev is not None:
                 ev[1].record()
             if world > 1:
-                ld.all_gather_costs(dJT.to(cdev), world * Bsz)   # RCCL all-gather of the cost curve
+                gather_costs()
         for _ in range(warmup):
             one_step()
+        if world > 1:
+            gather_flush()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         if world > 1:
             dist.barrier()
@@ -130,6 +153,7 @@ def main():
         for i in range(steps):
             one_step(evs[i])
         if world > 1:
+            gather_flush()
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -231,7 +255,7 @@ def main():
                                    + (f"closed-loop rollout T={T} (one launch = {Bsz}x{T} QP-steps)" if args.mode == "rollout"
                                       else "one-shot open-loop solve (one launch = one QP per system)"),
                        "mode": args.mode, "batch_per_gpu": Bsz, "T": T if args.mode == "rollout" else 1,
-                       "parallelism": f"dp{world} (independent shards, RCCL all-gather of J_T per step)" if world > 1 else "dp1",
+                       "parallelism": f"dp{world} (independent shards, RCCL all-gather of J_T per step, overlapped with the next step)" if world > 1 else "dp1",
                        "options": s.get_options(), "status_nonzero": status_bad},
             "roofline": roofline,
             "cpu_baseline": cpu,
