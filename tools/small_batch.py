@@ -2,7 +2,6 @@
 import os, sys, time, numpy as np
 sys.path.insert(0, '.')
 from lq_mpc_amd import BatchSolver, synth
-from oracle import oracle as orc
 s = BatchSolver(0)
 for cfg, Bsz in ((2, 1000), (3, 1000), (3, 4096), (3, 16384)):
     b = synth.make_batch(cfg, Bsz=Bsz)
