@@ -7,6 +7,7 @@
  *   lqmpc_solve_batch    <- LQ_MPC_Controller.solve          /root/reference/utils_class.py:48-91
  *                           (one call per instance there; Bsz instances per call here)
  *   lqmpc_rollout_batch  <- LQ_MPC_Simulator.simulate        /root/reference/utils_class.py:245-285
+ *   lqmpc_sweep_batch    <- one (error level | horizon) of data_generation: both of the following in one call
  *   lqmpc_max_vn_batch   <- the M_V loops of
  *                           LQ_RDP_Behavior_Multiple.data_generation
  *                                                            /root/reference/utils_class.py:813-824, 896-907
@@ -175,6 +176,26 @@ int lqmpc_max_vn_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, 
                            const double *lb, const double *ub, const double *x0s,
                            const double *x_ref, const double *u_ref,
                            double *dMV, int32_t *dstatus, int32_t *diters);
+
+/* ---- one horizon of the reference's sweep in one call: M_V over the K states x0s AND the closed-loop cost J_T from x0,
+ *      for the same (A,B,N) per instance (LQ_RDP_Behavior_Multiple.data_generation, utils_class.py:813-833, 896-916).
+ *      One kernel launch (condensing once per instance) where the 16-lane-row layout serves the shape and the batch has
+ *      at most 16 384 instances; otherwise lqmpc_max_vn_batch_dev followed by lqmpc_rollout_batch_dev on the stream.
+ *      status = the worse of the two parts, iters = their sum. ---- */
+int lqmpc_sweep_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int T, int K,
+                      const double *A, const double *B,
+                      const double *Q, const double *R, const double *P,
+                      const double *lb, const double *ub, const double *x0, const double *x0s,
+                      const double *A_true, const double *B_true, int true_per_instance,
+                      const double *x_ref, const double *u_ref,
+                      double *JT, double *MV, int32_t *status, int32_t *iters);
+int lqmpc_sweep_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int T, int K,
+                          const double *dA, const double *dB,
+                          const double *Q, const double *R, const double *P,
+                          const double *lb, const double *ub, const double *dx0, const double *x0s,
+                          const double *A_true, const double *B_true, int true_per_instance,
+                          const double *x_ref, const double *u_ref,
+                          double *dJT, double *dMV, int32_t *dstatus, int32_t *diters);
 
 /* ---- timing on the handle's stream (hipEvents), for bench.py's roofline ----
  * begin/end bracket any number of *_dev calls; end waits for the stream and returns the

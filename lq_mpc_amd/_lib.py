@@ -24,6 +24,7 @@ EXPORTS = [
     "lqmpc_solve_batch", "lqmpc_solve_batch_dev",
     "lqmpc_rollout_batch", "lqmpc_rollout_batch_dev",
     "lqmpc_max_vn_batch", "lqmpc_max_vn_batch_dev",
+    "lqmpc_sweep_batch", "lqmpc_sweep_batch_dev",
     "lqmpc_timer_begin", "lqmpc_timer_end",
 ]
 
@@ -86,6 +87,9 @@ def lib():
     mv_args = dims + [ctypes.c_int] + [P] * 13
     L.lqmpc_max_vn_batch.argtypes = mv_args
     L.lqmpc_max_vn_batch_dev.argtypes = mv_args
+    sweep_args = dims + [ctypes.c_int, ctypes.c_int] + [P] * 11 + [ctypes.c_int] + [P] * 6
+    L.lqmpc_sweep_batch.argtypes = sweep_args
+    L.lqmpc_sweep_batch_dev.argtypes = sweep_args
     L.lqmpc_timer_begin.argtypes = [_H]
     L.lqmpc_timer_end.argtypes = [_H, ctypes.POINTER(ctypes.c_float)]
     _lib = L

@@ -57,6 +57,7 @@ struct lqmpc_handle {
     DevBuf shared, ws;
     DevBuf key, key_sorted, idx, perm, cub_tmp, rec;   // difficulty ordering of rollout batches
     DevBuf fail;                     // r16 rollouts: [count | list] of the instances handed to the packed kernel
+    DevBuf st2, it2;                 // lqmpc_sweep_batch_dev without a fused kernel: status / iters of the max-V_N pass
     DevBuf stage[12];                // host-flavour staging (inputs and outputs)
     std::vector<double> shared_host; // last uploaded shared block
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -144,7 +145,7 @@ int lqmpc_destroy(lqmpc_handle *h)
     (void)hipStreamSynchronize(h->stream);
     if (h->shared.p) (void)hipFree(h->shared.p);
     if (h->ws.p) (void)hipFree(h->ws.p);
-    for (DevBuf *b : {&h->key, &h->key_sorted, &h->idx, &h->perm, &h->cub_tmp, &h->rec}) if (b->p) (void)hipFree(b->p);
+    for (DevBuf *b : {&h->key, &h->key_sorted, &h->idx, &h->perm, &h->cub_tmp, &h->rec, &h->fail, &h->st2, &h->it2}) if (b->p) (void)hipFree(b->p);
     for (auto &b : h->stage) if (b.p) (void)hipFree(b.p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -357,10 +358,23 @@ static int launch_r16_with_hand_back(lqmpc_handle *h, KParams &p)
     KParams f = p;
     f.perm = p.fail_list; f.count_dev = p.fail_count; f.fail_list = nullptr; f.fail_count = nullptr; f.nwide = 0;
     const char *name2 = nullptr;
+    if (p.mode == lqmpc::MODE_SWEEP) {         // the packed kernel has no fused mode: max V_N, then the rollout, over the list
+        f.mode = lqmpc::MODE_MAXVN;
+        if (!lqmpc::launch_spec(f, h->stream, &name2)) return fail(LQMPC_ERR_UNSUPPORTED, "hand-back launch failed");
+        f.mode = lqmpc::MODE_ROLLOUT;
+    }
     if (!lqmpc::launch_spec(f, h->stream, &name2)) return fail(LQMPC_ERR_UNSUPPORTED, "hand-back launch failed");
     HIP_TRY(hipGetLastError());
     h->last_kernel = name;
     return 0;
+}
+
+__global__ void lqmpc_merge_status_kernel(int *st, int *it, const int *st2, const int *it2, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (st) st[i] = st[i] > st2[i] ? st[i] : st2[i];
+    if (it) it[i] += it2[i];
 }
 
 extern "C" {
@@ -464,6 +478,47 @@ int lqmpc_max_vn_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, 
     p.A = dA; p.B = dB; p.MV = dMV; p.status = dstatus; p.iters = diters;
     if (use_spec(h, nx, nu, N) && use_r16(h, p, Bsz, 8192)) return launch_r16_with_hand_back(h, p);   // one-shot: setup-bound, crossover earlier
     return launch(h, p);
+}
+
+int lqmpc_sweep_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int T, int K, const double *dA, const double *dB,
+                          const double *Q, const double *R, const double *P, const double *lb, const double *ub,
+                          const double *dx0, const double *x0s, const double *A_true, const double *B_true,
+                          int true_per_instance, const double *x_ref, const double *u_ref, double *dJT, double *dMV,
+                          int32_t *dstatus, int32_t *diters)
+{
+    if (!h || !dA || !dB || !dx0 || !x0s || !dJT || !dMV || !A_true || !B_true) return fail(LQMPC_ERR_BAD_ARG, "NULL argument");
+    if (T < 1 || T > 100000) return fail(LQMPC_ERR_BAD_ARG, "T must be in [1,100000]");
+    if (K < 1 || K > 1024) return fail(LQMPC_ERR_BAD_ARG, "K must be in [1,1024]");
+    Call c{nx, nu, N, T, K, lqmpc::MODE_SWEEP, true_per_instance ? 1 : 0, Bsz, Q, R, P, lb, ub, x_ref, u_ref, A_true, B_true, x0s};
+    KParams p;
+    int rc = prepare(h, c, p);
+    if (rc) return rc;
+    if (use_spec(h, nx, nu, N) && use_r16(h, p, Bsz)) {
+        // one launch: condensing and W once per instance, K open-loop QPs, then the closed loop
+        p.A = dA; p.B = dB; p.x0 = dx0; p.JT = dJT; p.MV = dMV; p.status = dstatus; p.iters = diters;
+        if (true_per_instance) { p.At = A_true; p.Bt = B_true; }
+        const int order = h->opt.order < 0 ? ((T >= 4 && Bsz >= 1024) ? 1 : 0) : h->opt.order;
+        if (order) {
+            rc = build_order(h, p);
+            if (rc) return rc;
+        }
+        return launch_r16_with_hand_back(h, p);
+    }
+    // no fused kernel for this shape / size: the two launches, status = worse of the two, iters = their sum
+    int32_t *st2 = nullptr, *it2 = nullptr;
+    if (dstatus) { rc = ensure(h, h->st2, (size_t)Bsz * sizeof(int32_t)); if (rc) return rc; st2 = (int32_t *)h->st2.p; }
+    if (diters) { rc = ensure(h, h->it2, (size_t)Bsz * sizeof(int32_t)); if (rc) return rc; it2 = (int32_t *)h->it2.p; }
+    rc = lqmpc_max_vn_batch_dev(h, nx, nu, N, Bsz, K, dA, dB, Q, R, P, lb, ub, x0s, x_ref, u_ref, dMV, st2, it2);
+    if (rc) return rc;
+    rc = lqmpc_rollout_batch_dev(h, nx, nu, N, Bsz, T, dA, dB, Q, R, P, lb, ub, dx0, A_true, B_true, true_per_instance, x_ref, u_ref,
+                                 dJT, nullptr, nullptr, dstatus, diters);
+    if (rc) return rc;
+    if (dstatus || diters) {
+        hipLaunchKernelGGL(lqmpc_merge_status_kernel, dim3((unsigned)((Bsz + 255) / 256)), dim3(256), 0, h->stream, dstatus, diters,
+                           st2, it2, (long long)Bsz);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
 }
 
 }  // extern "C"
@@ -575,6 +630,32 @@ int lqmpc_max_vn_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int 
     rc = lqmpc_max_vn_batch_dev(h, nx, nu, N, Bsz, K, dA, dB, Q, R, P, lb, ub, x0s, x_ref, u_ref, dMV, dst, dit);
     if (rc) return rc;
     s.back(MV, dMV, b); s.back(status, dst, b); s.back(iters, dit, b);
+    if (s.rc) return s.rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int lqmpc_sweep_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int T, int K, const double *A, const double *B,
+                      const double *Q, const double *R, const double *P, const double *lb, const double *ub, const double *x0,
+                      const double *x0s, const double *A_true, const double *B_true, int true_per_instance, const double *x_ref,
+                      const double *u_ref, double *JT, double *MV, int32_t *status, int32_t *iters)
+{
+    if (!h || !A || !B || !x0 || !x0s || !JT || !MV || !A_true || !B_true) return fail(LQMPC_ERR_BAD_ARG, "NULL argument");
+    int rc = check_dims(nx, nu, N, Bsz);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    Stager s{h};
+    const size_t b = (size_t)Bsz;
+    const double *dA = s.in(A, b * nx * nx), *dB = s.in(B, b * nx * nu), *dx0 = s.in(x0, b * nx);
+    const double *dAt = A_true, *dBt = B_true;
+    if (true_per_instance) { dAt = s.in(A_true, b * nx * nx); dBt = s.in(B_true, b * nx * nu); }
+    double *dJT = s.out(JT, b), *dMV = s.out(MV, b);
+    int32_t *dst = s.out(status, b), *dit = s.out(iters, b);
+    if (s.rc) return s.rc;
+    rc = lqmpc_sweep_batch_dev(h, nx, nu, N, Bsz, T, K, dA, dB, Q, R, P, lb, ub, dx0, x0s, dAt, dBt, true_per_instance, x_ref, u_ref,
+                               dJT, dMV, dst, dit);
+    if (rc) return rc;
+    s.back(JT, dJT, b); s.back(MV, dMV, b); s.back(status, dst, b); s.back(iters, dit, b);
     if (s.rc) return s.rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;

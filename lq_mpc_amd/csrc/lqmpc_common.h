@@ -6,7 +6,7 @@
 
 namespace lqmpc {
 
-enum Mode : int { MODE_SOLVE = 0, MODE_ROLLOUT = 1, MODE_MAXVN = 2, MODE_PROBE = 3 };
+enum Mode : int { MODE_SOLVE = 0, MODE_ROLLOUT = 1, MODE_MAXVN = 2, MODE_PROBE = 3, MODE_SWEEP = 4 /* max V_N, then the rollout */ };
 
 // Offsets (in doubles) into the small "shared" device block that holds the data common to the
 // whole batch: Q, R, P, lb, ub, x_ref (nx,N), u_ref (nu,N), A_true, B_true, x0s (nx,K).

@@ -44,6 +44,7 @@ static void launch_r16_one(const KParams &p, hipStream_t stream)
     const dim3 grid((unsigned)((p.Bsz + 3) / 4));
     if (p.mode == MODE_SOLVE) hipLaunchKernelGGL((lqmpc_r16_kernel<NX, NU, N, MODE_SOLVE>), grid, dim3(64), 0, stream, p);
     else if (p.mode == MODE_MAXVN) hipLaunchKernelGGL((lqmpc_r16_kernel<NX, NU, N, MODE_MAXVN>), grid, dim3(64), 0, stream, p);
+    else if (p.mode == MODE_SWEEP) hipLaunchKernelGGL((lqmpc_r16_kernel<NX, NU, N, MODE_SWEEP>), grid, dim3(64), 0, stream, p);
     else {
 #ifdef LQMPC_R16_PROF
         long long z[16] = {0};

@@ -607,63 +607,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             u[k] = rowb(uk, row % 16);
         }
     };
-    if (MODE == MODE_ROLLOUT) {
-        // closed loop (utils_class.py:266-283)
-        double x[NX], Atm[NX][NX], Btm[NX][NU];
-#pragma unroll
-        for (int a = 0; a < NX; ++a) {
-            x[a] = p.rec ? p.rec[b * REC + NX * NX + NX * NU + a] : p.x0[(long long)a * Bsz + b];
-#pragma unroll
-            for (int c = 0; c < NX; ++c) Atm[a][c] = p.true_per_instance ? p.At[(long long)(a * NX + c) * Bsz + b] : sh[p.so.At + a * NX + c];
-#pragma unroll
-            for (int k = 0; k < NU; ++k) Btm[a][k] = p.true_per_instance ? p.Bt[(long long)(a * NU + k) * Bsz + b] : sh[p.so.Bt + a * NU + k];
-        }
-        double cost = 0.0;
-#pragma unroll
-        for (int a = 0; a < NX; ++a)
-#pragma unroll
-            for (int c = 0; c < NX; ++c) cost = __builtin_fma(x[a] * Qm[a][c], x[c], cost);
-        if (p.X && writer) {
-#pragma unroll
-            for (int a = 0; a < NX; ++a) p.X[((long long)a * (p.T + 1)) * Bsz + b] = x[a];
-        }
-        for (int t = 0; t < p.T; ++t) {
-            double v[RB], u[NU], xn[NX];
-            qp(x, v);
-            stage_input(v, 0, u);
-#pragma unroll
-            for (int a = 0; a < NX; ++a) {
-                double acc = 0.0;
-#pragma unroll
-                for (int c = 0; c < NX; ++c) acc = __builtin_fma(Atm[a][c], x[c], acc);
-#pragma unroll
-                for (int k = 0; k < NU; ++k) acc = __builtin_fma(Btm[a][k], u[k], acc);
-                xn[a] = acc;
-            }
-#pragma unroll
-            for (int a = 0; a < NX; ++a) x[a] = xn[a];
-#pragma unroll
-            for (int a = 0; a < NX; ++a)
-#pragma unroll
-                for (int c = 0; c < NX; ++c) cost = __builtin_fma(xn[a] * Qm[a][c], xn[c], cost);
-#pragma unroll
-            for (int k = 0; k < NU; ++k)
-#pragma unroll
-                for (int j = 0; j < NU; ++j) cost = __builtin_fma(u[k] * Rm[k][j], u[j], cost);
-            if (writer) {
-                if (p.X) {
-#pragma unroll
-                    for (int a = 0; a < NX; ++a) p.X[((long long)a * (p.T + 1) + t + 1) * Bsz + b] = xn[a];
-                }
-                if (p.U) {
-#pragma unroll
-                    for (int k = 0; k < NU; ++k) p.U[((long long)k * p.T + t) * Bsz + b] = u[k];
-                }
-            }
-        }
-        RPROF(7);
-        if (writer) p.JT[b] = cost;
-    } else {
+    if (MODE != MODE_ROLLOUT) {
         // open loop (utils_class.py:48-91): V_N by rolling the MODEL forward with the optimal inputs
         double Am[NX][NX], Bmm[NX][NU], Pm[NX][NX];
 #pragma unroll
@@ -739,6 +683,64 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             }
             if (writer) p.MV[b] = best;
         }
+    }
+    if (MODE == MODE_ROLLOUT || MODE == MODE_SWEEP) {
+        pL = 0; pU = 0;
+        // closed loop (utils_class.py:266-283)
+        double x[NX], Atm[NX][NX], Btm[NX][NU];
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+            x[a] = p.rec ? p.rec[b * REC + NX * NX + NX * NU + a] : p.x0[(long long)a * Bsz + b];
+#pragma unroll
+            for (int c = 0; c < NX; ++c) Atm[a][c] = p.true_per_instance ? p.At[(long long)(a * NX + c) * Bsz + b] : sh[p.so.At + a * NX + c];
+#pragma unroll
+            for (int k = 0; k < NU; ++k) Btm[a][k] = p.true_per_instance ? p.Bt[(long long)(a * NU + k) * Bsz + b] : sh[p.so.Bt + a * NU + k];
+        }
+        double cost = 0.0;
+#pragma unroll
+        for (int a = 0; a < NX; ++a)
+#pragma unroll
+            for (int c = 0; c < NX; ++c) cost = __builtin_fma(x[a] * Qm[a][c], x[c], cost);
+        if (p.X && writer) {
+#pragma unroll
+            for (int a = 0; a < NX; ++a) p.X[((long long)a * (p.T + 1)) * Bsz + b] = x[a];
+        }
+        for (int t = 0; t < p.T; ++t) {
+            double v[RB], u[NU], xn[NX];
+            qp(x, v);
+            stage_input(v, 0, u);
+#pragma unroll
+            for (int a = 0; a < NX; ++a) {
+                double acc = 0.0;
+#pragma unroll
+                for (int c = 0; c < NX; ++c) acc = __builtin_fma(Atm[a][c], x[c], acc);
+#pragma unroll
+                for (int k = 0; k < NU; ++k) acc = __builtin_fma(Btm[a][k], u[k], acc);
+                xn[a] = acc;
+            }
+#pragma unroll
+            for (int a = 0; a < NX; ++a) x[a] = xn[a];
+#pragma unroll
+            for (int a = 0; a < NX; ++a)
+#pragma unroll
+                for (int c = 0; c < NX; ++c) cost = __builtin_fma(xn[a] * Qm[a][c], xn[c], cost);
+#pragma unroll
+            for (int k = 0; k < NU; ++k)
+#pragma unroll
+                for (int j = 0; j < NU; ++j) cost = __builtin_fma(u[k] * Rm[k][j], u[j], cost);
+            if (writer) {
+                if (p.X) {
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) p.X[((long long)a * (p.T + 1) + t + 1) * Bsz + b] = xn[a];
+                }
+                if (p.U) {
+#pragma unroll
+                    for (int k = 0; k < NU; ++k) p.U[((long long)k * p.T + t) * Bsz + b] = u[k];
+                }
+            }
+        }
+        RPROF(7);
+        if (writer) p.JT[b] = cost;
     }
     if (writer) {
         if (p.status) p.status[b] = status;

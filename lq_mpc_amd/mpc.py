@@ -183,6 +183,29 @@ class BatchSolver:
                                               _ptr(MV), _ptr(status), _ptr(iters)))
         return {"M_V": MV, "status": status, "iters": iters}
 
+    def sweep_batch(self, T, N, A, B, Q, R, P, lb, ub, x0, x0s, A_true, B_true, x_ref=None, u_ref=None):
+        """One horizon of the reference's sweep (utils_class.py:813-833): M_V over the K columns of x0s and the closed-loop
+        cost J_T from x0, for the same models, in one call (one launch where the 16-lane-row layout serves the shape)."""
+        A, B, nx, nu, Bsz = self._dims(A, B)
+        Q, R, P = _f64(Q, (nx, nx)), _f64(R, (nu, nu)), _f64(P, (nx, nx))
+        lb, ub, x0 = _f64(lb, (nu,)), _f64(ub, (nu,)), _f64(x0, (nx, Bsz))
+        x0s = _f64(x0s)
+        if x0s.ndim != 2 or x0s.shape[0] != nx:
+            raise ValueError("x0s must be (nx, K)")
+        A_true, B_true = _f64(A_true), _f64(B_true)
+        per_inst = 1 if A_true.ndim == 3 else 0
+        if per_inst:
+            A_true, B_true = _f64(A_true, (nx, nx, Bsz)), _f64(B_true, (nx, nu, Bsz))
+        else:
+            A_true, B_true = _f64(A_true, (nx, nx)), _f64(B_true, (nx, nu))
+        x_ref, u_ref = _ref_or_none(x_ref, nx, N), _ref_or_none(u_ref, nu, N)
+        JT = np.empty(Bsz); MV = np.empty(Bsz)
+        status = np.empty(Bsz, dtype=np.int32); iters = np.empty(Bsz, dtype=np.int32)
+        _lib.check(self._L.lqmpc_sweep_batch(self._h, nx, nu, N, Bsz, T, x0s.shape[1], _ptr(A), _ptr(B), _ptr(Q), _ptr(R), _ptr(P),
+                                             _ptr(lb), _ptr(ub), _ptr(x0), _ptr(x0s), _ptr(A_true), _ptr(B_true), per_inst,
+                                             _ptr(x_ref), _ptr(u_ref), _ptr(JT), _ptr(MV), _ptr(status), _ptr(iters)))
+        return {"J_T": JT, "M_V": MV, "status": status, "iters": iters}
+
     # ---- device-pointer entry points (torch tensors / raw addresses already in HBM; asynchronous) ----
     def solve_batch_dev(self, nx, nu, N, Bsz, dA, dB, Q, R, P, lb, ub, dx0, du0, dVN, dstatus=None, diters=None,
                         x_ref=None, u_ref=None):

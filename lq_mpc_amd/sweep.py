@@ -104,9 +104,10 @@ class LQ_RDP_Behavior_Multiple:
         Bsz = A.shape[2]
         x0 = np.repeat(x_start[:, None], Bsz, axis=1)
         N = self.N_nominal
-        M_V_error = s.max_vn_batch(N, A, B, Q, R, Q, lb, ub, x0_vec, info_ref.get("x_ref"), info_ref.get("u_ref"))["M_V"]
-        J = s.rollout_batch(self.N_mpc, N, A, B, Q, R, Q, lb, ub, x0, self.A_true, self.B_true,
-                            info_ref.get("x_ref"), info_ref.get("u_ref"))["J_T"]
+        # M_V (8 open-loop solves per system) and the closed-loop cost share one launch: lqmpc_sweep_batch
+        res = s.sweep_batch(self.N_mpc, N, A, B, Q, R, Q, lb, ub, x0, x0_vec, self.A_true, self.B_true,
+                            info_ref.get("x_ref"), info_ref.get("u_ref"))
+        M_V_error, J = res["M_V"], res["J_T"]
         true_cost_error = J.reshape(self.N_sys, n_err)
         M_V_error = M_V_error.reshape(self.N_sys, n_err)
         # horizon sweep on error column index_sys = 4 (utils_class.py:880-883), zero references (887-888)
@@ -117,9 +118,8 @@ class LQ_RDP_Behavior_Multiple:
         M_V_horizon = np.zeros((self.N_sys, len(self.horizon)))
         for i, Nh in enumerate(self.horizon):
             Nh = int(Nh)
-            M_V_horizon[:, i] = s.max_vn_batch(Nh, A4, B4, Q, R, Q, lb, ub, x0_vec)["M_V"]
-            true_cost_horizon[:, i] = s.rollout_batch(self.N_mpc, Nh, A4, B4, Q, R, Q, lb, ub, x04,
-                                                      self.A_true, self.B_true)["J_T"]
+            res = s.sweep_batch(self.N_mpc, Nh, A4, B4, Q, R, Q, lb, ub, x04, x0_vec, self.A_true, self.B_true)
+            M_V_horizon[:, i], true_cost_horizon[:, i] = res["M_V"], res["J_T"]
         out = {"error": self.error_vec, "horizon": self.horizon, "V_expert": V_expert,
                "true_cost_error": true_cost_error, "true_cost_horizon": true_cost_horizon}
         if p is not None:

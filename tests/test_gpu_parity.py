@@ -410,3 +410,27 @@ def test_16_lane_row_layout_whole_batch_tiered_and_hand_back(solver, monkeypatch
             assert rel(g["J_T"], ref["J_T"]) < TIGHT and u_err(g["U"], ref["U"]) < RTOL and np.abs(g["X"] - ref["X"]).max() < 1e-7
     finally:
         solver.set_options(order=-1)
+
+
+def test_sweep_batch_is_max_vn_plus_rollout(solver, monkeypatch):
+    """lqmpc_sweep_batch = lqmpc_max_vn_batch + lqmpc_rollout_batch for the same models: fused in one launch on the
+    16-lane-row layout (C3 and the reference's shapes), two launches elsewhere (C4 shape here), also after a forced hand-back."""
+    for cfg, Bsz, fused in ((3, 1500, True), (2, 1000, True), (4, 96, False), (5, 24, False)):
+        b = synth.make_batch(cfg, Bsz=Bsz)
+        a = (b["N"], b["A"], b["B"], b["Q"], b["R"], b["P"], b["lb"], b["ub"])
+        x0s = np.ascontiguousarray(1.5 * b["x0"][:, :6])
+        mv = orc.max_vn_batch(*a, x0s)
+        jt = orc.rollout_batch(12, *a, b["x0"], b["A_true"], b["B_true"])["J_T"]
+        for cap in ((None, "1") if fused else (None,)):
+            if cap is None: monkeypatch.delenv("LQMPC_R16_MAXIT", raising=False)
+            else: monkeypatch.setenv("LQMPC_R16_MAXIT", cap)
+            g = solver.sweep_batch(12, *a, b["x0"], x0s, b["A_true"], b["B_true"])
+            assert ("r16" in solver.last_kernel()) == fused
+            assert np.all(g["status"] == 0)
+            assert rel(g["M_V"], mv) < TIGHT and rel(g["J_T"], jt) < TIGHT
+            if cap is None: g0 = g
+        monkeypatch.delenv("LQMPC_R16_MAXIT", raising=False)
+        m2 = solver.max_vn_batch(*a, x0s)
+        r2 = solver.rollout_batch(12, *a, b["x0"], b["A_true"], b["B_true"])
+        assert rel(g0["M_V"], m2["M_V"]) < 1e-12 and rel(g0["J_T"], r2["J_T"]) < 1e-12
+        assert np.array_equal(g0["iters"], m2["iters"] + r2["iters"])        # iters = the sum of the two parts
