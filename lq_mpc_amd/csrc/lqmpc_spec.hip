@@ -15,6 +15,9 @@
 // Algorithm (Spec::solve_qp): presolve -> primal-dual active-set warm start -> staged Mehrotra
 //   predictor-corrector interior point with active-set finishing.
 //
+// Sorted rollouts run in two tiers (lqmpc_spec_tiered_kernel below): the hardest instances of the order use the
+// 16-lane-row layout of lqmpc_r16_body.h, everything else the packed layout described here.
+//
 // Restates /root/reference/utils_class.py:48-91 (solve) and 245-285 (simulate); the solver replaces cvxpy's
 // QP back-end (utils_class.py:84-88).
 #include "lqmpc_common.h"
