@@ -21,6 +21,7 @@ bool launch_spec(const KParams &p, hipStream_t stream, const char **name);
 bool spec_tiered_available(int nx, int nu, int N);
 // lqmpc_r16.hip: rollouts with one instance per 16-lane row (n <= 32)
 bool r16_available(int nx, int nu, int N);
+int r16_lanes(int nx, int nu, int N);       // 16, 64 (one instance per wavefront: n > 32) or 0
 bool launch_r16(const KParams &p, hipStream_t stream, const char **name);
 // lqmpc_wg.hip: one instance per workgroup, 32 < n <= 128
 bool wg_supported(const KParams &p, const double *lb, const double *ub);
@@ -341,6 +342,7 @@ static bool use_r16(const lqmpc_handle *h, const KParams &p, int64_t Bsz, int64_
     const char *env = getenv("LQMPC_R16");
     const bool ok = h->opt.kernel == LQMPC_KERNEL_AUTO && p.presolve && p.warm_start && lqmpc::r16_available(p.nx, p.nu, p.N) &&
                     Bsz <= INT32_MAX;
+    if (ok && lqmpc::r16_lanes(p.nx, p.nu, p.N) == 64) return env ? env[0] == '1' : true;   // vs one wave per instance in the packed family too: always
     return ok && (env ? env[0] == '1' : Bsz <= limit);
 }
 

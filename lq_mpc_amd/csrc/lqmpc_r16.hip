@@ -25,32 +25,34 @@
 
 namespace lqmpc {
 
-template <int NX, int NU, int N, int MODE>
+template <int NX, int NU, int N, int MODE, int LPI>
 __global__ void __launch_bounds__(64, 1) lqmpc_r16_kernel(KParams p)
 {
-    __shared__ double lds_raw[4 * R16<NX, NU, N>::INST];
-    r16_body<NX, NU, N, MODE>(p, lds_raw, (long long)blockIdx.x * 4, p.Bsz);
+    using C = R16<NX, NU, N, LPI>;
+    __shared__ double lds_raw[C::IPW * C::INST];
+    r16_body<NX, NU, N, MODE, LPI>(p, lds_raw, (long long)blockIdx.x * C::IPW, p.Bsz);
 }
 
 struct R16Entry {
-    int nx, nu, N;
+    int nx, nu, N, lpi;
     const char *name;
     void (*launch)(const KParams &, hipStream_t);
 };
 
-template <int NX, int NU, int N>
+template <int NX, int NU, int N, int LPI>
 static void launch_r16_one(const KParams &p, hipStream_t stream)
 {
-    const dim3 grid((unsigned)((p.Bsz + 3) / 4));
-    if (p.mode == MODE_SOLVE) hipLaunchKernelGGL((lqmpc_r16_kernel<NX, NU, N, MODE_SOLVE>), grid, dim3(64), 0, stream, p);
-    else if (p.mode == MODE_MAXVN) hipLaunchKernelGGL((lqmpc_r16_kernel<NX, NU, N, MODE_MAXVN>), grid, dim3(64), 0, stream, p);
-    else if (p.mode == MODE_SWEEP) hipLaunchKernelGGL((lqmpc_r16_kernel<NX, NU, N, MODE_SWEEP>), grid, dim3(64), 0, stream, p);
+    constexpr int IPW = 64 / LPI;
+    const dim3 grid((unsigned)((p.Bsz + IPW - 1) / IPW));
+    if (p.mode == MODE_SOLVE) hipLaunchKernelGGL((lqmpc_r16_kernel<NX, NU, N, MODE_SOLVE, LPI>), grid, dim3(64), 0, stream, p);
+    else if (p.mode == MODE_MAXVN) hipLaunchKernelGGL((lqmpc_r16_kernel<NX, NU, N, MODE_MAXVN, LPI>), grid, dim3(64), 0, stream, p);
+    else if (p.mode == MODE_SWEEP) hipLaunchKernelGGL((lqmpc_r16_kernel<NX, NU, N, MODE_SWEEP, LPI>), grid, dim3(64), 0, stream, p);
     else {
 #ifdef LQMPC_R16_PROF
         long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_r16_prof), z, sizeof z);
 #endif
-        hipLaunchKernelGGL((lqmpc_r16_kernel<NX, NU, N, MODE_ROLLOUT>), grid, dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((lqmpc_r16_kernel<NX, NU, N, MODE_ROLLOUT, LPI>), grid, dim3(64), 0, stream, p);
 #ifdef LQMPC_R16_PROF
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_r16_prof), sizeof z);
@@ -60,12 +62,16 @@ static void launch_r16_one(const KParams &p, hipStream_t stream)
     }
 }
 
-#define R16E(NX, NU, N) {NX, NU, N, "lqmpc_r16_kernel<" #NX "," #NU "," #N ">", launch_r16_one<NX, NU, N>}
+#define R16E(NX, NU, N) {NX, NU, N, 16, "lqmpc_r16_kernel<" #NX "," #NU "," #N ">", launch_r16_one<NX, NU, N, 16>}
+#define R64E(NX, NU, N) {NX, NU, N, 64, "lqmpc_r64_kernel<" #NX "," #NU "," #N ">", launch_r16_one<NX, NU, N, 64>}
 static const R16Entry g_r16[] = {
     R16E(4, 2, 10),     // C3 (headline)
     R16E(2, 1, 10),     // C2
     R16E(2, 1, 5), R16E(2, 1, 6), R16E(2, 1, 7), R16E(2, 1, 8), R16E(2, 1, 9),   // C1 and the reference's horizon sweep
     R16E(2, 1, 20), R16E(2, 1, 30),   // mpc_test.py (N_open = 20), V_expert (N_opc = 30)
+    // R64E(4, 2, 20): C4 (n = 40) with one instance per wavefront and v_readlane broadcasts (LPI = 64) passes the parity tests
+    // but is 18 % slower than lqmpc_spec_kernel<4,2,20,64> (45.6 ms vs 38.8 ms per launch): its unrolled condensing spills
+    // 2.9 KB per lane.  Parked until that is fixed.
 };
 
 static const R16Entry *find_r16(int nx, int nu, int N)
@@ -76,6 +82,7 @@ static const R16Entry *find_r16(int nx, int nu, int N)
 }
 
 bool r16_available(int nx, int nu, int N) { return find_r16(nx, nu, N) != nullptr; }
+int r16_lanes(int nx, int nu, int N) { const R16Entry *e = find_r16(nx, nu, N); return e ? e->lpi : 0; }
 
 bool launch_r16(const KParams &p, hipStream_t stream, const char **name)
 {

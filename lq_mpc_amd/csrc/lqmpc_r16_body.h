@@ -26,31 +26,74 @@ __device__ long long g_r16_prof[16];
 #define RPROF_START do { } while (0)
 #endif
 
-template <int NX, int NU, int N>
+typedef unsigned long long mask_t;        // one bit per row of an instance (n <= 64)
+
+// LPI = lanes per instance: 16 (four instances per wavefront, row broadcasts by DPP row_newbcast) or 64 (one instance
+// per wavefront for 32 < n <= 48, row broadcasts by v_readlane: the value becomes a scalar operand)
+template <int NX, int NU, int N, int LPI = 16>
 struct R16 {
     static constexpr int n = N * NU;
-    static constexpr int RB = (n + 15) / 16;
+    static constexpr int RB = (n + LPI - 1) / LPI;
+    static constexpr int IPW = 64 / LPI;              // instances per wavefront
+    static constexpr int CS = (LPI == 16) ? 16 : 24;  // most unknowns of a gathered system: min(|A|, |F|) <= n / 2
     static constexpr int LDW = n + 1;                // row stride of P and W: odd, so that a column read is conflict-free
     static constexpr int PK = n * LDW;               // both stored in full: every access below is row base + constant
-    static constexpr int VEC = 16 * RB;
-    // LDS per instance, in doubles: P | W | r | x | y | list (16 ints)
+    static constexpr int VEC = LPI * RB;
+    // LDS per instance, in doubles: P | W | r | x | y | list (CS ints)
     static constexpr int oP = 0, oW = PK, oR = 2 * PK, oX = oR + VEC, oY = oX + VEC, oL = oY + VEC;
-    static constexpr int oD = oL + 8;                 // a dummy slot: predicated LDS stores go there instead of toggling exec
+    static constexpr int oD = oL + CS / 2;                 // a dummy slot: predicated LDS stores go there instead of toggling exec
     static constexpr int SETUP = oW + 3 * n * NX + N * NX * NX;          // condensing tables alias the W region and what follows
     static constexpr int INST = (oD + 2 > SETUP) ? oD + 2 : SETUP;
     static constexpr int MAXIT = 12;
-    static_assert(n <= 32, "one or two row slots per lane");
+    static_assert(LPI == 16 || LPI == 64, "a DPP row or the whole wavefront");
+    static_assert((n + 1) / 2 <= CS && n <= 64, "the smaller side must fit the gathered system");
 };
 
 
+// ---- the per-instance primitives in the two mappings ----
+// ballot over the lanes of my instance
+template <int LPI>
+__device__ __forceinline__ mask_t iballot(bool c, int q)
+{
+    if constexpr (LPI == 16) return (__ballot(c) >> (16 * q)) & 0xFFFFull;
+    else return __ballot(c);
+}
+// value of lane k of my instance (k: compile-time constant after unrolling)
+template <int LPI>
+__device__ __forceinline__ double ibcast(double x, int k)
+{
+    if constexpr (LPI == 16) return rowb(x, k);
+    else return wg::rdlane(x, k);
+}
+// acc += (lane k's x) * y
+template <int LPI>
+__device__ __forceinline__ void ifmac(double &acc, double x, double y, int k)
+{
+    if constexpr (LPI == 16) fmac_rowb(acc, x, y, k);
+    else acc = __builtin_fma(wg::rdlane(x, k), y, acc);
+}
+// acc += (lane k's acc) * y
+template <int LPI>
+__device__ __forceinline__ void ifmac_self(double &acc, double y, int k)
+{
+    if constexpr (LPI == 16) fmac_rowb_self(acc, y, k);
+    else acc = __builtin_fma(wg::rdlane(acc, k), y, acc);
+}
+template <int LPI>
+__device__ __forceinline__ void isettle(double &x)
+{
+    if constexpr (LPI == 16) dpp_settle(x);
+}
+
+// One wavefront's work: the four instances in slots slot0 .. slot0 + 3 (slots >= slot_end are surplus).
 // One pivot of the in-place Gauss-Jordan inversion (K is a template parameter so that every register index and
 // DPP control below is a constant: the optimizer does not fully unroll a loop of this size on its own).
-template <int K, int RB, int n>
+template <int K, int RB, int n, int LPI>
 __device__ __forceinline__ void gj_invert_step(double (&M)[RB][n], const int (&rw)[RB], bool &spd)
 {
-    constexpr int sk = K / 16, lk = K % 16;
-    dpp_settle(M[sk][K]);
-    const double d = rowb(M[sk][K], lk);
+    constexpr int sk = K / LPI, lk = K % LPI;
+    isettle<LPI>(M[sk][K]);
+    const double d = ibcast<LPI>(M[sk][K], lk);
     spd = spd && (d > 0.0);
     const double inv = frcp(d);
     double g[RB];
@@ -64,15 +107,15 @@ __device__ __forceinline__ void gj_invert_step(double (&M)[RB][n], const int (&r
     for (int j = 0; j < n; ++j) {
 #pragma unroll
         for (int s = 0; s < RB; ++s)
-            if (s != sk) fmac_rowb(M[s][j], M[sk][j], g[s], lk);     // the pivot row's own slot last: it rescales the row the others read
-        if (j == K) fmac_rowb(M[sk][j], M[sk][j], g[sk], lk);       // (column K was written just above: DPP wait states)
-        else fmac_rowb_self(M[sk][j], g[sk], lk);
+            if (s != sk) ifmac<LPI>(M[s][j], M[sk][j], g[s], lk);     // the pivot row's own slot last: it rescales the row the others read
+        if (j == K) ifmac<LPI>(M[sk][j], M[sk][j], g[sk], lk);       // (column K was written just above: DPP wait states)
+        else ifmac_self<LPI>(M[sk][j], g[sk], lk);
     }
 }
-template <int RB, int n, int... K>
+template <int RB, int n, int LPI, int... K>
 __device__ __forceinline__ void gj_invert(double (&M)[RB][n], const int (&rw)[RB], bool &spd, std::integer_sequence<int, K...>)
 {
-    (gj_invert_step<K, RB, n>(M, rw, spd), ...);
+    (gj_invert_step<K, RB, n, LPI>(M, rw, spd), ...);
 }
 
 // compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, CNT - 1>)
@@ -81,17 +124,14 @@ __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int
 template <int CNT, typename F>
 __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, CNT>{}); }
 
-// the 16 bits of a wave ballot that belong to my 16-lane row
-__device__ __forceinline__ unsigned ballot16(bool c, int q) { return (unsigned)((__ballot(c) >> (16 * q)) & 0xFFFFull); }
-
-// One wavefront's work: the four instances in slots slot0 .. slot0 + 3 (slots >= slot_end are surplus).
-template <int NX, int NU, int N, int MODE>
+template <int NX, int NU, int N, int MODE, int LPI = 16>
 __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long long slot0, long long slot_end)
 {
-    using C = R16<NX, NU, N>;
+    using C = R16<NX, NU, N, LPI>;
+    constexpr int CS = C::CS;
     constexpr int n = C::n, RB = C::RB, LDW = C::LDW;
     constexpr int REC = NX * NX + NX * NU + NX;
-    const int lane = threadIdx.x, q = lane >> 4, i = lane & 15;
+    const int lane = threadIdx.x, q = lane / LPI, i = lane % LPI;
     ldsd *L = (ldsd *)lds_raw + q * C::INST;
     ldsd *Pp = L + C::oP, *Wp = L + C::oW, *rL = L + C::oR, *xL = L + C::oX, *yL = L + C::oY;
     ldsi *list = (ldsi *)(L + C::oL);
@@ -102,14 +142,14 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     const long long slot = valid ? b_raw : slot_end - 1;
     const long long b = p.perm ? (long long)p.perm[slot] : slot;
     const double *sh = p.sh;
-    const unsigned nmask = (n == 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    const mask_t nmask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
 
     int rw[RB];
     bool vrow[RB];
     double h[RB], ctr[RB];
 #pragma unroll
     for (int s = 0; s < RB; ++s) {
-        rw[s] = i + 16 * s;
+        rw[s] = i + LPI * s;
         vrow[s] = rw[s] < n;
         const int k = rw[s] % NU;
         h[s] = vrow[s] ? 0.5 * (sh[p.so.ub + k] - sh[p.so.lb + k]) : 1.0;
@@ -223,7 +263,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             for (int a = 0; a < NX; ++a) man[a] = nxt ? MA[(rw[s] + NU) * NX + a] : 0.0;
 #pragma unroll
             for (int j = 0; j < n; ++j) {
-                if (j > 16 * s + 15) continue;                   // static: no row of this slot reaches column j
+                if (j > LPI * s + LPI - 1) continue;                   // static: no row of this slot reaches column j
                 double t = 0.0;
 #pragma unroll
                 for (int a = 0; a < NX; ++a) t = __builtin_fma(ma[s][a], PM[j * NX + a], t);
@@ -244,10 +284,10 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
             for (int j = 0; j < n; ++j) {
                 double acc = 0.0;
-                if (j <= 16 * s + 15) {
+                if (j <= LPI * s + LPI - 1) {
 #pragma unroll
                     for (int d = 0; d < N; ++d) {
-                        if (16 * s + d * NU >= n) continue;      // static: beyond the last row for every row of this slot
+                        if (LPI * s + d * NU >= n) continue;      // static: beyond the last row for every row of this slot
                         const bool in = vrow[s] && j <= rw[s] && rw[s] + d * NU < n;
                         const double t = Pp[in ? (rw[s] + d * NU) * LDW + j + d * NU : 0];
                         acc += in ? t : 0.0;
@@ -263,7 +303,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             const int bi = rw[s] / NU, ui = rw[s] % NU;
 #pragma unroll
             for (int j = 0; j < n; ++j) {
-                if (j > 16 * s + 15) continue;
+                if (j > LPI * s + LPI - 1) continue;
                 const double val = 2.0 * (Wr[s][j] + ((j / NU == bi) ? sh[p.so.R + ui * NU + (j % NU)] : 0.0));
                 Wr[s][j] = val;
                 Pp[(vrow[s] && j <= rw[s]) ? rw[s] * LDW + j : DUMMY] = val;
@@ -301,7 +341,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 for (int c = 0; c < NX; ++c) Apw[a][c] = AP[(N - 1 - d) * NX * NX + a * NX + c];
 #pragma unroll
             for (int s = 0; s < RB; ++s) {
-                if (16 * s + d * NU >= n) continue;              // static: beyond the last row for every row of this slot
+                if (LPI * s + d * NU >= n) continue;              // static: beyond the last row for every row of this slot
                 const bool in = vrow[s] && rw[s] + d * NU < n;
                 double wmv[NX];
 #pragma unroll
@@ -387,7 +427,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         // the pivot row itself); column k is set to e_k first so that it ends up holding column k of the inverse.
         bool spd = true;
         RPROF(4);
-        gj_invert<RB, n>(Wr, rw, spd, std::make_integer_sequence<int, n>{});
+        gj_invert<RB, n, LPI>(Wr, rw, spd, std::make_integer_sequence<int, n>{});
         RPROF(5);
         // [G | v_r] = -W [Fq | qr]: row i of W is in my registers, row j of [Fq | qr] comes by row broadcast
 #pragma unroll
@@ -397,13 +437,13 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             for (int a = 0; a < NX; ++a) G[s][a] = 0.0;
         }
         static_for<n>([&](auto jc) {                        // (a plain loop with the DPP switch inside is not fully unrolled)
-            constexpr int j = decltype(jc)::value, sj = j / 16, lj = j % 16;
+            constexpr int j = decltype(jc)::value, sj = j / LPI, lj = j % LPI;
 #pragma unroll
             for (int s = 0; s < RB; ++s) {
                 const double nw = -Wr[s][j];
 #pragma unroll
-                for (int a = 0; a < NX; ++a) fmac_rowb(G[s][a], Facc[sj][a], nw, lj);
-                if (has_lin) fmac_rowb(vr[s], qr[sj], nw, lj);
+                for (int a = 0; a < NX; ++a) ifmac<LPI>(G[s][a], Facc[sj][a], nw, lj);
+                if (has_lin) ifmac<LPI>(vr[s], qr[sj], nw, lj);
             }
         });
 #pragma unroll
@@ -438,12 +478,12 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
         for (int j = 0; j < NU; ++j) Rm[k][j] = sh[p.so.R + k * NU + j];
     const bool writer = valid && i == 0;
-    unsigned pL = 0, pU = 0;                  // active set of the previous step (row-uniform bit masks)
+    mask_t pL = 0, pU = 0;                  // active set of the previous step (row-uniform bit masks)
     int iters = 0, status = 0;
     // ---- one box QP at state x: v <- the optimum (my rows); updates the warm-start face, iters, status ----
     auto qp = [&](const double (&x)[NX], double (&v)[RB]) {
         double vu[RB];
-        unsigned cl = 0, cu = 0;
+        mask_t cl = 0, cu = 0;
         bool bad = false;
 #pragma unroll
         for (int s = 0; s < RB; ++s) {
@@ -451,17 +491,17 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
             for (int a = 0; a < NX; ++a) acc = __builtin_fma(G[s][a], x[a], acc);
             vu[s] = acc; v[s] = acc;
-            cl |= ballot16(vrow[s] && acc < -h[s], q) << (16 * s);
-            cu |= ballot16(vrow[s] && acc > h[s], q) << (16 * s);
+            cl |= iballot<LPI>(vrow[s] && acc < -h[s], q) << (LPI * s);
+            cu |= iballot<LPI>(vrow[s] && acc > h[s], q) << (LPI * s);
             bad = bad || (vrow[s] && !(fabs(acc) < 1e300));
         }
-        const bool rowbad = ballot16(bad, q) != 0;
+        const bool rowbad = iballot<LPI>(bad, q) != 0;
         bool busy = ((cl | cu) != 0) && !rowbad;              // row-uniform
-        unsigned mL = 0, mU = 0;
+        mask_t mL = 0, mU = 0;
         if (busy) {
             if (p.warm_start && (pL | pU) != 0) {
                 // the previous face shifted by one stage; the last stage keeps its flags
-                const unsigned top = nmask & ~(nmask >> NU);
+                const mask_t top = nmask & ~(nmask >> NU);
                 mL = (pL >> NU) | (pL & top);
                 mU = (pU >> NU) | (pU & top);
             } else {
@@ -472,30 +512,30 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         if (__ballot(busy) != 0ull) {
 #pragma unroll 1
             for (int it = 0; it < p.r16_maxit; ++it) {
-                const unsigned mA = mL | mU;
-                const int m = __popc(mA);
+                const mask_t mA = mL | mU;
+                const int m = __popcll(mA);
                 const bool dual = 2 * m <= n;                     // row-uniform: the smaller side
-                const unsigned mC = busy ? (dual ? mA : (~mA & nmask)) : 0u;
-                const int c = __popc(mC);
+                const mask_t mC = busy ? (dual ? mA : (~mA & nmask)) : 0ull;
+                const int c = __popcll(mC);
                 int cw = c;                                      // wave maximum: uniform loop bound
-                cw = max(cw, __shfl_xor(cw, 16)); cw = max(cw, __shfl_xor(cw, 32));
+                if (LPI == 16) { cw = max(cw, __shfl_xor(cw, 16)); cw = max(cw, __shfl_xor(cw, 32)); }
                 cw = __builtin_amdgcn_readfirstlane(cw);
                 const bool any_primal = __ballot(busy && !dual) != 0ull;
                 // publish v_unc, r = v_unc - s h on the active rows (0 elsewhere), the list of the chosen side
 #pragma unroll
                 for (int s = 0; s < RB; ++s) {
-                    const unsigned bit = 1u << rw[s];
+                    const mask_t bit = 1ull << rw[s];
                     const double sg = (mL & bit) ? -1.0 : ((mU & bit) ? 1.0 : 0.0);
                     rL[rw[s]] = (sg != 0.0) ? vu[s] - sg * h[s] : 0.0;
                     xL[rw[s]] = 0.0;
-                    if (vrow[s] && (mC & bit)) list[__popc(mC & (bit - 1u))] = rw[s];
+                    if (vrow[s] && (mC & bit)) list[__popcll(mC & (bit - 1ull))] = rw[s];
                 }
                 __syncthreads();
                 const ldsd *Mx = dual ? Wp : Pp;
                 const int la = (i < c) ? list[i] : 0;
-                double S[16], rhs;
+                double S[CS], rhs;
 #pragma unroll
-                for (int bg = 0; bg < 4; ++bg) {                 // columns in groups of four: one uniform test per group
+                for (int bg = 0; bg < CS / 4; ++bg) {            // columns in groups of four: one uniform test per group
 #pragma unroll
                     for (int bb = 4 * bg; bb < 4 * bg + 4; ++bb) S[bb] = (bb == i) ? 1.0 : 0.0;
                     if (4 * bg < cw) {
@@ -516,26 +556,26 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 }
                 // Gauss-Jordan on [S | rhs]: afterwards S = I and rhs = the solution
                 bool ok = true;
-                static_for<16>([&](auto kc) {                    // (compile-time pivot index: the DPP control is an immediate)
+                static_for<CS>([&](auto kc) {                    // (compile-time pivot index: the DPP control is an immediate)
                     constexpr int k = decltype(kc)::value;
                     if (k < cw) {                                // uniform
-                        dpp_settle(S[k]);
-                        const double d = rowb(S[k], k);
+                        isettle<LPI>(S[k]);
+                        const double d = ibcast<LPI>(S[k], k);
                         ok = ok && (d > 0.0);
                         const double inv = frcp(d);
                         const double g = (i == k) ? (inv - 1.0) : -S[k] * inv;
 #pragma unroll
-                        for (int jg = 0; jg < 4; ++jg) {         // columns in groups of four: one uniform test per group
+                        for (int jg = 0; jg < CS / 4; ++jg) {    // columns in groups of four: one uniform test per group
                             if (4 * jg + 3 > k && 4 * jg < cw) {  // first half static, second uniform
 #pragma unroll
                                 for (int j = 4 * jg; j < 4 * jg + 4; ++j)
-                                    if (j > k) fmac_rowb_self(S[j], g, k);
+                                    if (j > k) ifmac_self<LPI>(S[j], g, k);
                             }
                         }
-                        fmac_rowb_self(rhs, g, k);
+                        ifmac_self<LPI>(rhs, g, k);
                     }
                 });
-                const bool rowfail = ballot16(!ok, q) != 0;
+                const bool rowfail = iballot<LPI>(!ok, q) != 0;
                 if (i < c) xL[la] = rhs;
                 __syncthreads();
                 double xs_[RB];
@@ -553,7 +593,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                     const ldsd *Mrow = Mx + (vrow[s] ? rw[s] : 0) * LDW;
 #pragma unroll
                     for (int j = 0; j < n; ++j) tt = __builtin_fma(Mrow[j], yL[j], tt);
-                    const unsigned bit = 1u << rw[s];
+                    const mask_t bit = 1ull << rw[s];
                     const bool act = vrow[s] && (mA & bit);
                     const double sg = (mL & bit) ? -1.0 : 1.0;
                     const double xs = xs_[s];
@@ -565,20 +605,21 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 }
                 tol = fmax(tol, __shfl_xor(tol, 1)); tol = fmax(tol, __shfl_xor(tol, 2));
                 tol = fmax(tol, __shfl_xor(tol, 4)); tol = fmax(tol, __shfl_xor(tol, 8));
+                if (LPI == 64) { tol = fmax(tol, __shfl_xor(tol, 16)); tol = fmax(tol, __shfl_xor(tol, 32)); }
                 tol *= 1e-10;
-                unsigned nL = 0, nU = 0;
+                mask_t nL = 0, nU = 0;
                 bool nf = false;
 #pragma unroll
                 for (int s = 0; s < RB; ++s) {
-                    const unsigned bit = 1u << rw[s];
+                    const mask_t bit = 1ull << rw[s];
                     const bool act = vrow[s] && (mA & bit);
                     const bool lo = act ? ((mL & bit) && gl[s] >= -tol) : (vrow[s] && v[s] < -h[s] * (1.0 + 1e-12));
                     const bool up = act ? ((mU & bit) && gl[s] <= tol) : (vrow[s] && v[s] > h[s] * (1.0 + 1e-12));
-                    nL |= ballot16(lo, q) << (16 * s);
-                    nU |= ballot16(up, q) << (16 * s);
+                    nL |= iballot<LPI>(lo, q) << (LPI * s);
+                    nU |= iballot<LPI>(up, q) << (LPI * s);
                     nf = nf || (vrow[s] && !(fabs(v[s]) < 1e300));
                 }
-                const bool rownf = ballot16(nf, q) != 0;
+                const bool rownf = iballot<LPI>(nf, q) != 0;
                 if (busy) {
                     iters += 1;
                     if (rowfail || rownf) { failed = true; busy = false; }
@@ -603,8 +644,8 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
         for (int k = 0; k < NU; ++k) {
             const int row = st * NU + k;                         // compile-time after unrolling
-            const double uk = fmin(fmax(v[row / 16], -h[row / 16]), h[row / 16]) + ctr[row / 16];
-            u[k] = rowb(uk, row % 16);
+            const double uk = fmin(fmax(v[row / LPI], -h[row / LPI]), h[row / LPI]) + ctr[row / LPI];
+            u[k] = ibcast<LPI>(uk, row % LPI);
         }
     };
     if (MODE != MODE_ROLLOUT) {
