@@ -69,9 +69,7 @@ static const R16Entry g_r16[] = {
     R16E(2, 1, 10),     // C2
     R16E(2, 1, 5), R16E(2, 1, 6), R16E(2, 1, 7), R16E(2, 1, 8), R16E(2, 1, 9),   // C1 and the reference's horizon sweep
     R16E(2, 1, 20), R16E(2, 1, 30),   // mpc_test.py (N_open = 20), V_expert (N_opc = 30)
-    // R64E(4, 2, 20): C4 (n = 40) with one instance per wavefront and v_readlane broadcasts (LPI = 64) passes the parity tests
-    // but is 18 % slower than lqmpc_spec_kernel<4,2,20,64> (45.6 ms vs 38.8 ms per launch): its unrolled condensing spills
-    // 2.9 KB per lane.  Parked until that is fixed.
+    R64E(4, 2, 20),     // C4 (n = 40): one instance per wavefront (LPI = 64), same algorithm, v_readlane broadcasts
 };
 
 static const R16Entry *find_r16(int nx, int nu, int N)

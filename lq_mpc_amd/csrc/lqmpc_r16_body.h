@@ -129,6 +129,10 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 {
     using C = R16<NX, NU, N, LPI>;
     constexpr int CS = C::CS;
+    // Unrolling of the three horizon-length loops of the condensing.  Fully unrolled they are fastest (N <= 10: C2, C3, 3-5 %)
+    // but the scheduler then hoists every LDS load to the top and spills (128 VGPRs at C3, 900 at N = 20); partly rolled
+    // the longer horizons compile without a single spill and run faster than with them (C4: 25.7 ms against 45.6 ms).
+    constexpr int UNR_CHAIN = (N <= 10) ? N : 1, UNR_SUFFIX = (N <= 10) ? N : 4, UNR_FQ = (N <= 10) ? N : 2;
     constexpr int n = C::n, RB = C::RB, LDW = C::LDW;
     constexpr int REC = NX * NX + NX * NU + NX;
     const int lane = threadIdx.x, q = lane / LPI, i = lane % LPI;
@@ -189,7 +193,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
                 for (int c = 0; c < NX; ++c) Ap[a][c] = A[a][c];
             }
-#pragma unroll
+#pragma unroll (UNR_CHAIN)                       // nothing below is indexed by m at compile time
             for (int m = 0; m < N; ++m) {
                 if (m > 0) {
                     double T[NX][NU], T2[NX][NX];
@@ -285,9 +289,9 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             for (int j = 0; j < n; ++j) {
                 double acc = 0.0;
                 if (j <= LPI * s + LPI - 1) {
-#pragma unroll
-                    for (int d = 0; d < N; ++d) {
-                        if (LPI * s + d * NU >= n) continue;      // static: beyond the last row for every row of this slot
+                    const int dcnt = (n - LPI * s + NU - 1) / NU;        // terms of the longest diagonal of this slot (constant after unrolling s)
+#pragma unroll (UNR_SUFFIX)                              // bounds how far ahead the loads can be hoisted
+                    for (int d = 0; d < (dcnt < N ? dcnt : N); ++d) {
                         const bool in = vrow[s] && j <= rw[s] && rw[s] + d * NU < n;
                         const double t = Pp[in ? (rw[s] + d * NU) * LDW + j + d * NU : 0];
                         acc += in ? t : 0.0;
@@ -332,7 +336,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         for (int s = 0; s < RB; ++s)
 #pragma unroll
             for (int c = 0; c < NX; ++c) Facc[s][c] = 0.0;
-#pragma unroll
+#pragma unroll (UNR_FQ)
         for (int d = 0; d < N; ++d) {
             double Apw[NX][NX];
 #pragma unroll
@@ -341,7 +345,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 for (int c = 0; c < NX; ++c) Apw[a][c] = AP[(N - 1 - d) * NX * NX + a * NX + c];
 #pragma unroll
             for (int s = 0; s < RB; ++s) {
-                if (LPI * s + d * NU >= n) continue;              // static: beyond the last row for every row of this slot
+                if (LPI * s + d * NU >= n) continue;              // uniform: beyond the last row for every row of this slot
                 const bool in = vrow[s] && rw[s] + d * NU < n;
                 double wmv[NX];
 #pragma unroll
