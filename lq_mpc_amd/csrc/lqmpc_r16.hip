@@ -26,7 +26,7 @@
 namespace lqmpc {
 
 template <int NX, int NU, int N, int MODE, int LPI>
-__global__ void __launch_bounds__(64, (N * NU <= 10 && LPI == 16) ? 2 : 1) lqmpc_r16_kernel(KParams p)
+__global__ void __launch_bounds__(64, ((N * NU <= 10 && LPI == 16) || LPI == 64) ? 2 : 1) lqmpc_r16_kernel(KParams p)
 {
     using C = R16<NX, NU, N, LPI>;
     __shared__ double lds_raw[C::IPW * C::INST];
