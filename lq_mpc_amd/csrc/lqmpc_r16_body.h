@@ -193,7 +193,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
                 for (int c = 0; c < NX; ++c) Ap[a][c] = A[a][c];
             }
-#pragma unroll (UNR_CHAIN)                       // nothing below is indexed by m at compile time
+#pragma unroll UNR_CHAIN                         // nothing below is indexed by m at compile time
             for (int m = 0; m < N; ++m) {
                 if (m > 0) {
                     double T[NX][NU], T2[NX][NX];
@@ -290,7 +290,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 double acc = 0.0;
                 if (j <= LPI * s + LPI - 1) {
                     const int dcnt = (n - LPI * s + NU - 1) / NU;        // terms of the longest diagonal of this slot (constant after unrolling s)
-#pragma unroll (UNR_SUFFIX)                              // bounds how far ahead the loads can be hoisted
+#pragma unroll UNR_SUFFIX                                // bounds how far ahead the loads can be hoisted
                     for (int d = 0; d < (dcnt < N ? dcnt : N); ++d) {
                         const bool in = vrow[s] && j <= rw[s] && rw[s] + d * NU < n;
                         const double t = Pp[in ? (rw[s] + d * NU) * LDW + j + d * NU : 0];
@@ -336,7 +336,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         for (int s = 0; s < RB; ++s)
 #pragma unroll
             for (int c = 0; c < NX; ++c) Facc[s][c] = 0.0;
-#pragma unroll (UNR_FQ)
+#pragma unroll UNR_FQ
         for (int d = 0; d < N; ++d) {
             double Apw[NX][NX];
 #pragma unroll
