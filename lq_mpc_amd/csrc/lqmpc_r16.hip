@@ -25,12 +25,20 @@
 
 namespace lqmpc {
 
+// Register budget: two waves per SIMD (256 registers) where the code fits them -- the n <= 10 shapes and the one-instance-
+// per-wavefront mapping as they are, the rollout of the larger 16-lane shapes in its low-register build (OCC = 2).
 template <int NX, int NU, int N, int MODE, int LPI>
-__global__ void __launch_bounds__(64, ((N * NU <= 10 && LPI == 16) || LPI == 64) ? 2 : 1) lqmpc_r16_kernel(KParams p)
+struct R16Build {
+    static constexpr int OCC = (LPI == 16 && N * NU > 10 && MODE == MODE_ROLLOUT) ? 2 : 1;
+    static constexpr int WAVES = (OCC == 2 || N * NU <= 10 || LPI == 64) ? 2 : 1;
+};
+
+template <int NX, int NU, int N, int MODE, int LPI>
+__global__ void __launch_bounds__(64, (R16Build<NX, NU, N, MODE, LPI>::WAVES)) lqmpc_r16_kernel(KParams p)
 {
     using C = R16<NX, NU, N, LPI>;
     __shared__ double lds_raw[C::IPW * C::INST];
-    r16_body<NX, NU, N, MODE, LPI>(p, lds_raw, (long long)blockIdx.x * C::IPW, p.Bsz);
+    r16_body<NX, NU, N, MODE, LPI, R16Build<NX, NU, N, MODE, LPI>::OCC>(p, lds_raw, (long long)blockIdx.x * C::IPW, p.Bsz);
 }
 
 struct R16Entry {

@@ -41,7 +41,9 @@ struct R16 {
     static constexpr int VEC = LPI * RB;
     // LDS per instance, in doubles: P | W | r | x | y | list (CS ints)
     static constexpr int oP = 0, oW = PK, oR = 2 * PK, oX = oR + VEC, oY = oX + VEC, oL = oY + VEC;
-    static constexpr int oD = oL + CS / 2;                 // a dummy slot: predicated LDS stores go there instead of toggling exec
+    static constexpr int oC = oL + CS / 2;            // Q | R | A_true | B_true (read from LDS when built for two waves per SIMD)
+    static constexpr int CN = 2 * NX * NX + NU * NU + NX * NU;
+    static constexpr int oD = oC + CN + (CN & 1);                 // a dummy slot: predicated LDS stores go there instead of toggling exec
     static constexpr int SETUP = oW + 3 * n * NX + N * NX * NX;          // condensing tables alias the W region and what follows
     static constexpr int INST = (oD + 2 > SETUP) ? oD + 2 : SETUP;
     static constexpr int MAXIT = 12;
@@ -124,7 +126,10 @@ __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int
 template <int CNT, typename F>
 __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, CNT>{}); }
 
-template <int NX, int NU, int N, int MODE, int LPI = 16>
+// OCC = 2: built for two waves per SIMD (256 registers): the horizon loops of the condensing stay rolled and the stage weights
+// and the plant live in LDS instead of registers (they are the loop-invariant values the allocator would otherwise reload
+// from scratch in every step).
+template <int NX, int NU, int N, int MODE, int LPI = 16, int OCC = 1>
 __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long long slot0, long long slot_end)
 {
     using C = R16<NX, NU, N, LPI>;
@@ -132,7 +137,8 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     // Unrolling of the three horizon-length loops of the condensing.  Fully unrolled they are fastest (N <= 10: C2, C3, 3-5 %)
     // but the scheduler then hoists every LDS load to the top and spills (128 VGPRs at C3, 900 at N = 20); partly rolled
     // the longer horizons compile without a single spill and run faster than with them (C4: 25.7 ms against 45.6 ms).
-    constexpr int UNR_CHAIN = (N <= 10) ? N : 1, UNR_SUFFIX = (N <= 10) ? N : 4, UNR_FQ = (N <= 10) ? N : 2;
+    constexpr bool UNROLL = (N <= 10) && OCC == 1;
+    constexpr int UNR_CHAIN = UNROLL ? N : 1, UNR_SUFFIX = UNROLL ? N : 4, UNR_FQ = UNROLL ? N : 2;
     constexpr int n = C::n, RB = C::RB, LDW = C::LDW;
     constexpr int REC = NX * NX + NX * NU + NX;
     const int lane = threadIdx.x, q = lane / LPI, i = lane % LPI;
@@ -472,15 +478,49 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 
     // ---------------- the requested operation ----------------
     // stage weights once: inside the step loop they would be vector loads per step
-    double Qm[NX][NX], Rm[NU][NU];
+    double Qm[NX][NX], Rm[NU][NU], Atm[NX][NX], Btm[NX][NU];
+    ldsd *cQ = L + C::oC, *cR = cQ + NX * NX, *cAt = cR + NU * NU, *cBt = cAt + NX * NX;
+    if constexpr (OCC == 2) {
+        if (i == 0) {
 #pragma unroll
-    for (int a = 0; a < NX; ++a)
+            for (int a = 0; a < NX; ++a) {
 #pragma unroll
-        for (int c = 0; c < NX; ++c) Qm[a][c] = sh[p.so.Q + a * NX + c];
+                for (int c = 0; c < NX; ++c) {
+                    cQ[a * NX + c] = sh[p.so.Q + a * NX + c];
+                    cAt[a * NX + c] = p.true_per_instance ? p.At[(long long)(a * NX + c) * Bsz + b] : sh[p.so.At + a * NX + c];
+                }
 #pragma unroll
-    for (int k = 0; k < NU; ++k)
+                for (int k = 0; k < NU; ++k) cBt[a * NU + k] = p.true_per_instance ? p.Bt[(long long)(a * NU + k) * Bsz + b] : sh[p.so.Bt + a * NU + k];
+            }
 #pragma unroll
-        for (int j = 0; j < NU; ++j) Rm[k][j] = sh[p.so.R + k * NU + j];
+            for (int k = 0; k < NU; ++k)
+#pragma unroll
+                for (int j = 0; j < NU; ++j) cR[k * NU + j] = sh[p.so.R + k * NU + j];
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+#pragma unroll
+            for (int c = 0; c < NX; ++c) {
+                Qm[a][c] = sh[p.so.Q + a * NX + c];
+                if (MODE == MODE_ROLLOUT || MODE == MODE_SWEEP)
+                    Atm[a][c] = p.true_per_instance ? p.At[(long long)(a * NX + c) * Bsz + b] : sh[p.so.At + a * NX + c];
+            }
+            if (MODE == MODE_ROLLOUT || MODE == MODE_SWEEP) {
+#pragma unroll
+                for (int k = 0; k < NU; ++k) Btm[a][k] = p.true_per_instance ? p.Bt[(long long)(a * NU + k) * Bsz + b] : sh[p.so.Bt + a * NU + k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NU; ++k)
+#pragma unroll
+            for (int j = 0; j < NU; ++j) Rm[k][j] = sh[p.so.R + k * NU + j];
+    }
+    auto Qv = [&](int a, int c) -> double { if constexpr (OCC == 2) return cQ[a * NX + c]; else return Qm[a][c]; };
+    auto Rv = [&](int k, int j) -> double { if constexpr (OCC == 2) return cR[k * NU + j]; else return Rm[k][j]; };
+    auto Atv = [&](int a, int c) -> double { if constexpr (OCC == 2) return cAt[a * NX + c]; else return Atm[a][c]; };
+    auto Btv = [&](int a, int k) -> double { if constexpr (OCC == 2) return cBt[a * NU + k]; else return Btm[a][k]; };
     const bool writer = valid && i == 0;
     mask_t pL = 0, pU = 0;                  // active set of the previous step (row-uniform bit masks)
     int iters = 0, status = 0;
@@ -672,7 +712,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
             for (int a = 0; a < NX; ++a)
 #pragma unroll
-                for (int cc = 0; cc < NX; ++cc) c = __builtin_fma(xs[a] * Qm[a][cc], xs[cc], c);
+                for (int cc = 0; cc < NX; ++cc) c = __builtin_fma(xs[a] * Qv(a, cc), xs[cc], c);
             static_for<N>([&](auto kc) {
                 constexpr int st = decltype(kc)::value;
                 double u[NU], xn[NX];
@@ -691,7 +731,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
                 for (int a = 0; a < NX; ++a)
 #pragma unroll
-                    for (int cc = 0; cc < NX; ++cc) c = __builtin_fma(xn[a] * ((st == N - 1) ? Pm[a][cc] : Qm[a][cc]), xn[cc], c);
+                    for (int cc = 0; cc < NX; ++cc) c = __builtin_fma(xn[a] * ((st == N - 1) ? Pm[a][cc] : Qv(a, cc)), xn[cc], c);
                 if (p.has_ref) {
 #pragma unroll
                     for (int k = 0; k < NU; ++k) u[k] -= sh[p.so.uref + k * N + st];
@@ -699,7 +739,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
                 for (int k = 0; k < NU; ++k)
 #pragma unroll
-                    for (int j = 0; j < NU; ++j) c = __builtin_fma(u[k] * Rm[k][j], u[j], c);
+                    for (int j = 0; j < NU; ++j) c = __builtin_fma(u[k] * Rv(k, j), u[j], c);
             });
             return c;
         };
@@ -732,20 +772,14 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     if (MODE == MODE_ROLLOUT || MODE == MODE_SWEEP) {
         pL = 0; pU = 0;
         // closed loop (utils_class.py:266-283)
-        double x[NX], Atm[NX][NX], Btm[NX][NU];
+        double x[NX];
 #pragma unroll
-        for (int a = 0; a < NX; ++a) {
-            x[a] = p.rec ? p.rec[b * REC + NX * NX + NX * NU + a] : p.x0[(long long)a * Bsz + b];
-#pragma unroll
-            for (int c = 0; c < NX; ++c) Atm[a][c] = p.true_per_instance ? p.At[(long long)(a * NX + c) * Bsz + b] : sh[p.so.At + a * NX + c];
-#pragma unroll
-            for (int k = 0; k < NU; ++k) Btm[a][k] = p.true_per_instance ? p.Bt[(long long)(a * NU + k) * Bsz + b] : sh[p.so.Bt + a * NU + k];
-        }
+        for (int a = 0; a < NX; ++a) x[a] = p.rec ? p.rec[b * REC + NX * NX + NX * NU + a] : p.x0[(long long)a * Bsz + b];
         double cost = 0.0;
 #pragma unroll
         for (int a = 0; a < NX; ++a)
 #pragma unroll
-            for (int c = 0; c < NX; ++c) cost = __builtin_fma(x[a] * Qm[a][c], x[c], cost);
+            for (int c = 0; c < NX; ++c) cost = __builtin_fma(x[a] * Qv(a, c), x[c], cost);
         if (p.X && writer) {
 #pragma unroll
             for (int a = 0; a < NX; ++a) p.X[((long long)a * (p.T + 1)) * Bsz + b] = x[a];
@@ -758,9 +792,9 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             for (int a = 0; a < NX; ++a) {
                 double acc = 0.0;
 #pragma unroll
-                for (int c = 0; c < NX; ++c) acc = __builtin_fma(Atm[a][c], x[c], acc);
+                for (int c = 0; c < NX; ++c) acc = __builtin_fma(Atv(a, c), x[c], acc);
 #pragma unroll
-                for (int k = 0; k < NU; ++k) acc = __builtin_fma(Btm[a][k], u[k], acc);
+                for (int k = 0; k < NU; ++k) acc = __builtin_fma(Btv(a, k), u[k], acc);
                 xn[a] = acc;
             }
 #pragma unroll
@@ -768,11 +802,11 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
             for (int a = 0; a < NX; ++a)
 #pragma unroll
-                for (int c = 0; c < NX; ++c) cost = __builtin_fma(xn[a] * Qm[a][c], xn[c], cost);
+                for (int c = 0; c < NX; ++c) cost = __builtin_fma(xn[a] * Qv(a, c), xn[c], cost);
 #pragma unroll
             for (int k = 0; k < NU; ++k)
 #pragma unroll
-                for (int j = 0; j < NU; ++j) cost = __builtin_fma(u[k] * Rm[k][j], u[j], cost);
+                for (int j = 0; j < NU; ++j) cost = __builtin_fma(u[k] * Rv(k, j), u[j], cost);
             if (writer) {
                 if (p.X) {
 #pragma unroll
