@@ -36,7 +36,7 @@ struct R16Build {
 template <int NX, int NU, int N, int MODE, int LPI>
 __global__ void __launch_bounds__(64, (R16Build<NX, NU, N, MODE, LPI>::WAVES)) lqmpc_r16_kernel(KParams p)
 {
-    using C = R16<NX, NU, N, LPI>;
+    using C = R16<NX, NU, N, LPI, (R16Build<NX, NU, N, MODE, LPI>::OCC == 2)>;
     __shared__ double lds_raw[C::IPW * C::INST];
     r16_body<NX, NU, N, MODE, LPI, R16Build<NX, NU, N, MODE, LPI>::OCC>(p, lds_raw, (long long)blockIdx.x * C::IPW, p.Bsz);
 }

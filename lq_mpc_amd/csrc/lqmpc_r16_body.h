@@ -30,22 +30,25 @@ typedef unsigned long long mask_t;        // one bit per row of an instance (n <
 
 // LPI = lanes per instance: 16 (four instances per wavefront, row broadcasts by DPP row_newbcast) or 64 (one instance
 // per wavefront for 32 < n <= 48, row broadcasts by v_readlane: the value becomes a scalar operand)
-template <int NX, int NU, int N, int LPI = 16>
+template <int NX, int NU, int N, int LPI = 16, bool PACKED = false>
 struct R16 {
     static constexpr int n = N * NU;
     static constexpr int RB = (n + LPI - 1) / LPI;
     static constexpr int IPW = 64 / LPI;              // instances per wavefront
     static constexpr int CS = (LPI == 16) ? 16 : 24;  // most unknowns of a gathered system: min(|A|, |F|) <= n / 2
     static constexpr int LDW = n + 1;                // row stride of P and W: odd, so that a column read is conflict-free
-    static constexpr int PK = n * LDW;               // both stored in full: every access below is row base + constant
+    // P and W: full rows (every access is row base + constant) or, for the builds that need the LDS for a second wave per
+    // SIMD, the packed lower triangle (an address select per access)
+    static constexpr int PK = PACKED ? n * (n + 1) / 2 : n * LDW;
     static constexpr int VEC = LPI * RB;
     // LDS per instance, in doubles: P | W | r | x | y | list (CS ints)
     static constexpr int oP = 0, oW = PK, oR = 2 * PK, oX = oR + VEC, oY = oX + VEC, oL = oY + VEC;
     static constexpr int oC = oL + CS / 2;            // Q | R | A_true | B_true (read from LDS when built for two waves per SIMD)
     static constexpr int CN = 2 * NX * NX + NU * NU + NX * NU;
-    static constexpr int oD = oC + CN + (CN & 1);                 // a dummy slot: predicated LDS stores go there instead of toggling exec
     static constexpr int SETUP = oW + 3 * n * NX + N * NX * NX;          // condensing tables alias the W region and what follows
-    static constexpr int INST = (oD + 2 > SETUP) ? oD + 2 : SETUP;
+    static constexpr int END = oC + CN + (CN & 1);
+    static constexpr int oD = (END > SETUP) ? END : SETUP;        // a dummy slot BEHIND both: predicated LDS stores go there instead of toggling exec
+    static constexpr int INST = oD + 2;
     static constexpr int MAXIT = 12;
     static_assert(LPI == 16 || LPI == 64, "a DPP row or the whole wavefront");
     static_assert((n + 1) / 2 <= CS && n <= 64, "the smaller side must fit the gathered system");
@@ -132,7 +135,8 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make
 template <int NX, int NU, int N, int MODE, int LPI = 16, int OCC = 1>
 __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long long slot0, long long slot_end)
 {
-    using C = R16<NX, NU, N, LPI>;
+    constexpr bool PACKED = (OCC == 2);
+    using C = R16<NX, NU, N, LPI, PACKED>;
     constexpr int CS = C::CS;
     // Unrolling of the three horizon-length loops of the condensing.  Fully unrolled they are fastest (N <= 10: C2, C3, 3-5 %)
     // but the scheduler then hoists every LDS load to the top and spills (128 VGPRs at C3, 900 at N = 20); partly rolled
@@ -154,17 +158,25 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     const double *sh = p.sh;
     const mask_t nmask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
 
-    int rw[RB];
+    int rw[RB], tri[RB];
     bool vrow[RB];
     double h[RB], ctr[RB];
 #pragma unroll
     for (int s = 0; s < RB; ++s) {
         rw[s] = i + LPI * s;
+        tri[s] = rw[s] * (rw[s] + 1) / 2;
         vrow[s] = rw[s] < n;
         const int k = rw[s] % NU;
         h[s] = vrow[s] ? 0.5 * (sh[p.so.ub + k] - sh[p.so.lb + k]) : 1.0;
         ctr[s] = vrow[s] ? 0.5 * (sh[p.so.ub + k] + sh[p.so.lb + k]) : 0.0;
     }
+
+    // element (r, j) of P or W for a row r of mine (tr = r (r + 1) / 2) and any column j; (a, b) for two run-time indices
+    auto ad = [&](int r, int tr, int j) -> int { if constexpr (PACKED) return (j <= r) ? tr + j : j * (j + 1) / 2 + r; else return r * LDW + j; };
+    auto ad2 = [&](int a, int b2) -> int {
+        if constexpr (PACKED) { const int hi = a > b2 ? a : b2, lo = a > b2 ? b2 : a; return hi * (hi + 1) / 2 + lo; }
+        else return a * LDW + b2;
+    };
 
     // ---------------- condensing (utils_class.py:62-75 in matrix form) ----------------
     // Row i = bi*NU + ui has a = N-1-bi stages to go; with ma_i = column ui of M_a = A^a B,
@@ -281,7 +293,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
                     for (int a = 0; a < NX; ++a) t = __builtin_fma(man[a], QM[(j + NU) * NX + a] - PM[(j + NU) * NX + a], t);
                 }
-                Pp[(vrow[s] && j <= rw[s]) ? rw[s] * LDW + j : DUMMY] = t;
+                Pp[(vrow[s] && j <= rw[s]) ? ad(rw[s], tri[s], j) : DUMMY] = t;
                 if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // straight-line code: keep the loads near their use
             }
         }
@@ -299,7 +311,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll UNR_SUFFIX                                // bounds how far ahead the loads can be hoisted
                     for (int d = 0; d < (dcnt < N ? dcnt : N); ++d) {
                         const bool in = vrow[s] && j <= rw[s] && rw[s] + d * NU < n;
-                        const double t = Pp[in ? (rw[s] + d * NU) * LDW + j + d * NU : 0];
+                        const double t = Pp[in ? ad2(rw[s] + d * NU, j + d * NU) : 0];
                         acc += in ? t : 0.0;
                     }
                 }
@@ -316,7 +328,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 if (j > LPI * s + LPI - 1) continue;
                 const double val = 2.0 * (Wr[s][j] + ((j / NU == bi) ? sh[p.so.R + ui * NU + (j % NU)] : 0.0));
                 Wr[s][j] = val;
-                Pp[(vrow[s] && j <= rw[s]) ? rw[s] * LDW + j : DUMMY] = val;
+                Pp[(vrow[s] && j <= rw[s]) ? ad(rw[s], tri[s], j) : DUMMY] = val;
             }
         }
         __syncthreads();
@@ -324,7 +336,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         for (int s = 0; s < RB; ++s)
 #pragma unroll
             for (int j = 0; j < n; ++j) {
-                const double up = Pp[(vrow[s] && j > rw[s]) ? j * LDW + rw[s] : 0];
+                const double up = Pp[(vrow[s] && j > rw[s]) ? ad2(j, rw[s]) : 0];
                 Wr[s][j] = vrow[s] ? ((j > rw[s]) ? up : Wr[s][j]) : 0.0;
                 if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
             }
@@ -333,7 +345,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         for (int s = 0; s < RB; ++s)
 #pragma unroll
             for (int j = 0; j < n; ++j)
-                Pp[(vrow[s] && j > rw[s]) ? rw[s] * LDW + j : DUMMY] = Wr[s][j];   // the upper triangle: rows are stored in full
+                if (!PACKED) Pp[(vrow[s] && j > rw[s]) ? rw[s] * LDW + j : DUMMY] = Wr[s][j];   // the upper triangle: rows are stored in full
         RPROF(2);
         __builtin_amdgcn_sched_barrier(0);
         // Fq rows: power by power (d outer), so that each A^(N-d) is fetched once for both row slots
@@ -460,7 +472,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         for (int s = 0; s < RB; ++s) {
 #pragma unroll
             for (int j = 0; j < n; ++j)
-                Wp[vrow[s] ? rw[s] * LDW + j : DUMMYW] = Wr[s][j];
+                Wp[(vrow[s] && (!PACKED || j <= rw[s])) ? ad(rw[s], tri[s], j) : DUMMYW] = Wr[s][j];
             if (!vrow[s]) {
                 vr[s] = 0.0;
 #pragma unroll
@@ -576,7 +588,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 }
                 __syncthreads();
                 const ldsd *Mx = dual ? Wp : Pp;
-                const int la = (i < c) ? list[i] : 0;
+                const int la = (i < c) ? list[i] : 0, tla = la * (la + 1) / 2;
                 double S[CS], rhs;
 #pragma unroll
                 for (int bg = 0; bg < CS / 4; ++bg) {            // columns in groups of four: one uniform test per group
@@ -586,7 +598,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
                         for (int bb = 4 * bg; bb < 4 * bg + 4; ++bb) {
                             const int lb = (bb < c) ? list[bb] : 0;
-                            const double val = Mx[la * LDW + lb];
+                            const double val = Mx[ad2(la, lb)];
                             if (i < c && bb < c) S[bb] = val;
                         }
                     }
@@ -595,7 +607,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 if (any_primal) {
                     double tp = 0.0;
 #pragma unroll
-                    for (int j = 0; j < n; ++j) tp = __builtin_fma(Pp[la * LDW + j], rL[j], tp);
+                    for (int j = 0; j < n; ++j) tp = __builtin_fma(Pp[ad(la, tla, j)], rL[j], tp);
                     if (i < c && !dual) rhs = tp;
                 }
                 // Gauss-Jordan on [S | rhs]: afterwards S = I and rhs = the solution
@@ -634,9 +646,9 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
                 for (int s = 0; s < RB; ++s) {
                     double tt = 0.0;
-                    const ldsd *Mrow = Mx + (vrow[s] ? rw[s] : 0) * LDW;
+                    const int mr = vrow[s] ? rw[s] : 0, mt = vrow[s] ? tri[s] : 0;
 #pragma unroll
-                    for (int j = 0; j < n; ++j) tt = __builtin_fma(Mrow[j], yL[j], tt);
+                    for (int j = 0; j < n; ++j) tt = __builtin_fma(Mx[ad(mr, mt, j)], yL[j], tt);
                     const mask_t bit = 1ull << rw[s];
                     const bool act = vrow[s] && (mA & bit);
                     const double sg = (mL & bit) ? -1.0 : 1.0;
