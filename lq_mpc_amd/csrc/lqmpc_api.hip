@@ -333,11 +333,12 @@ static int launch(lqmpc_handle *h, const KParams &p)
     return 0;
 }
 
-// Which layout (measured at C3 / C2 shapes): up to 16 384 instances the packed kernel does not
-// fill the GPU (16 or 32 instances per wavefront) and the 16-lane-row kernel takes the whole batch; above that sorted
-// rollouts run in two tiers, the 16-lane-row layout for their hardest 4 096 instances.  LQMPC_R16=0/1 forces the
-// choice (development switch).
-static bool use_r16(const lqmpc_handle *h, const KParams &p, int64_t Bsz, int64_t limit = 16384)
+// Which layout (measured at C3 / C2 shapes).  Rollouts: the 16-lane-row kernel (two waves per SIMD,
+// P and W packed in LDS) for every batch size -- 0.77 ms against 0.97 ms for the two-tier launch of the packed kernel at
+// C3's 65 536 instances, and it also fills the GPU where the packed kernel (16 or 32 instances per wavefront) cannot.
+// One-shot entry points and the fused sweep (built for one wave per SIMD): up to `limit` instances.
+// LQMPC_R16=0/1 forces the choice (development switch; 0 gives the packed kernel and its two-tier launch).
+static bool use_r16(const lqmpc_handle *h, const KParams &p, int64_t Bsz, int64_t limit)
 {
     const char *env = getenv("LQMPC_R16");
     const bool ok = h->opt.kernel == LQMPC_KERNEL_AUTO && p.presolve && p.warm_start && lqmpc::r16_available(p.nx, p.nu, p.N) &&
@@ -429,7 +430,7 @@ int lqmpc_rollout_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
     if (true_per_instance) { p.At = A_true; p.Bt = B_true; }
     const bool spec = use_spec(h, nx, nu, N);
     const int order = h->opt.order < 0 ? ((spec && p.presolve && T >= 4 && Bsz >= 1024) ? 1 : 0) : (spec ? h->opt.order : 0);
-    if (spec && use_r16(h, p, Bsz)) {
+    if (spec && use_r16(h, p, Bsz, INT32_MAX)) {
         const int r16_order = h->opt.order < 0 ? ((T >= 4 && Bsz >= 1024) ? 1 : 0) : h->opt.order;
         if (r16_order) {
             rc = build_order(h, p);
@@ -495,7 +496,7 @@ int lqmpc_sweep_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, i
     KParams p;
     int rc = prepare(h, c, p);
     if (rc) return rc;
-    if (use_spec(h, nx, nu, N) && use_r16(h, p, Bsz)) {
+    if (use_spec(h, nx, nu, N) && use_r16(h, p, Bsz, 16384)) {
         // one launch: condensing and W once per instance, K open-loop QPs, then the closed loop
         p.A = dA; p.B = dB; p.x0 = dx0; p.JT = dJT; p.MV = dMV; p.status = dstatus; p.iters = diters;
         if (true_per_instance) { p.At = A_true; p.Bt = B_true; }

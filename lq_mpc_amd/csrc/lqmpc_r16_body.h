@@ -160,15 +160,11 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 
     int rw[RB], tri[RB];
     bool vrow[RB];
-    double h[RB], ctr[RB];
 #pragma unroll
     for (int s = 0; s < RB; ++s) {
         rw[s] = i + LPI * s;
         tri[s] = rw[s] * (rw[s] + 1) / 2;
         vrow[s] = rw[s] < n;
-        const int k = rw[s] % NU;
-        h[s] = vrow[s] ? 0.5 * (sh[p.so.ub + k] - sh[p.so.lb + k]) : 1.0;
-        ctr[s] = vrow[s] ? 0.5 * (sh[p.so.ub + k] + sh[p.so.lb + k]) : 0.0;
     }
 
     // element (r, j) of P or W for a row r of mine (tr = r (r + 1) / 2) and any column j; (a, b) for two run-time indices
@@ -393,14 +389,16 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         if (has_lin) {
             if (p.has_ref) {
                 //   d_r = -xref_r,  lam_r = Q_r d_r + A' lam_{r+1},  gref_r = B' lam_r - R uref_r   (columns r <-> x_{r+1}, u_r)
+                long long br = b;
+                asm volatile("" : "+v"(br));
                 double lam[NX], A2[NX][NX], B2[NX][NU];       // the model again: not kept live across the condensing above
 #pragma unroll
                 for (int a = 0; a < NX; ++a) {
                     lam[a] = 0.0;
 #pragma unroll
-                    for (int c = 0; c < NX; ++c) A2[a][c] = p.rec ? p.rec[b * REC + a * NX + c] : p.A[(long long)(a * NX + c) * Bsz + b];
+                    for (int c = 0; c < NX; ++c) A2[a][c] = p.rec ? p.rec[br * REC + a * NX + c] : p.A[(long long)(a * NX + c) * Bsz + br];
 #pragma unroll
-                    for (int k = 0; k < NU; ++k) B2[a][k] = p.rec ? p.rec[b * REC + NX * NX + a * NU + k] : p.B[(long long)(a * NU + k) * Bsz + b];
+                    for (int k = 0; k < NU; ++k) B2[a][k] = p.rec ? p.rec[br * REC + NX * NX + a * NU + k] : p.B[(long long)(a * NU + k) * Bsz + br];
                 }
 #pragma unroll 1
                 for (int r = N - 1; r >= 0; --r) {
@@ -489,6 +487,18 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     RPROF_START;
 
     // ---------------- the requested operation ----------------
+    // an opaque copy of the instance index for everything below: the addresses derived from it are recomputed here instead of
+    // being kept (spilled) across the whole set-up
+    long long bq = b;
+    asm volatile("" : "+v"(bq));
+    // (the box of my rows is fetched here, not at the top: nothing of the set-up above needs it and it would only be spilled)
+    double h[RB], ctr[RB];
+#pragma unroll
+    for (int s = 0; s < RB; ++s) {
+        const int k = rw[s] % NU;
+        h[s] = vrow[s] ? 0.5 * (sh[p.so.ub + k] - sh[p.so.lb + k]) : 1.0;
+        ctr[s] = vrow[s] ? 0.5 * (sh[p.so.ub + k] + sh[p.so.lb + k]) : 0.0;
+    }
     // stage weights once: inside the step loop they would be vector loads per step
     double Qm[NX][NX], Rm[NU][NU], Atm[NX][NX], Btm[NX][NU];
     ldsd *cQ = L + C::oC, *cR = cQ + NX * NX, *cAt = cR + NU * NU, *cBt = cAt + NX * NX;
@@ -499,10 +509,10 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
                 for (int c = 0; c < NX; ++c) {
                     cQ[a * NX + c] = sh[p.so.Q + a * NX + c];
-                    cAt[a * NX + c] = p.true_per_instance ? p.At[(long long)(a * NX + c) * Bsz + b] : sh[p.so.At + a * NX + c];
+                    cAt[a * NX + c] = p.true_per_instance ? p.At[(long long)(a * NX + c) * Bsz + bq] : sh[p.so.At + a * NX + c];
                 }
 #pragma unroll
-                for (int k = 0; k < NU; ++k) cBt[a * NU + k] = p.true_per_instance ? p.Bt[(long long)(a * NU + k) * Bsz + b] : sh[p.so.Bt + a * NU + k];
+                for (int k = 0; k < NU; ++k) cBt[a * NU + k] = p.true_per_instance ? p.Bt[(long long)(a * NU + k) * Bsz + bq] : sh[p.so.Bt + a * NU + k];
             }
 #pragma unroll
             for (int k = 0; k < NU; ++k)
@@ -517,11 +527,11 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             for (int c = 0; c < NX; ++c) {
                 Qm[a][c] = sh[p.so.Q + a * NX + c];
                 if (MODE == MODE_ROLLOUT || MODE == MODE_SWEEP)
-                    Atm[a][c] = p.true_per_instance ? p.At[(long long)(a * NX + c) * Bsz + b] : sh[p.so.At + a * NX + c];
+                    Atm[a][c] = p.true_per_instance ? p.At[(long long)(a * NX + c) * Bsz + bq] : sh[p.so.At + a * NX + c];
             }
             if (MODE == MODE_ROLLOUT || MODE == MODE_SWEEP) {
 #pragma unroll
-                for (int k = 0; k < NU; ++k) Btm[a][k] = p.true_per_instance ? p.Bt[(long long)(a * NU + k) * Bsz + b] : sh[p.so.Bt + a * NU + k];
+                for (int k = 0; k < NU; ++k) Btm[a][k] = p.true_per_instance ? p.Bt[(long long)(a * NU + k) * Bsz + bq] : sh[p.so.Bt + a * NU + k];
             }
         }
 #pragma unroll
@@ -711,11 +721,11 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         for (int a = 0; a < NX; ++a) {
 #pragma unroll
             for (int c = 0; c < NX; ++c) {
-                Am[a][c] = p.rec ? p.rec[b * REC + a * NX + c] : p.A[(long long)(a * NX + c) * Bsz + b];
+                Am[a][c] = p.rec ? p.rec[bq * REC + a * NX + c] : p.A[(long long)(a * NX + c) * Bsz + bq];
                 Pm[a][c] = sh[p.so.P + a * NX + c];
             }
 #pragma unroll
-            for (int k = 0; k < NU; ++k) Bmm[a][k] = p.rec ? p.rec[b * REC + NX * NX + a * NU + k] : p.B[(long long)(a * NU + k) * Bsz + b];
+            for (int k = 0; k < NU; ++k) Bmm[a][k] = p.rec ? p.rec[bq * REC + NX * NX + a * NU + k] : p.B[(long long)(a * NU + k) * Bsz + bq];
         }
         auto value_fn = [&](const double (&x0v)[NX], const double (&v)[RB]) -> double {
             double xs[NX], c = 0.0;
@@ -758,14 +768,14 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         if (MODE == MODE_SOLVE) {
             double x[NX], v[RB], u[NU];
 #pragma unroll
-            for (int a = 0; a < NX; ++a) x[a] = p.rec ? p.rec[b * REC + NX * NX + NX * NU + a] : p.x0[(long long)a * Bsz + b];
+            for (int a = 0; a < NX; ++a) x[a] = p.rec ? p.rec[bq * REC + NX * NX + NX * NU + a] : p.x0[(long long)a * Bsz + bq];
             qp(x, v);
             const double vn = value_fn(x, v);
             stage_input(v, 0, u);
             if (writer) {
                 p.VN[b] = vn;
 #pragma unroll
-                for (int k = 0; k < NU; ++k) p.u0[(long long)k * Bsz + b] = u[k];
+                for (int k = 0; k < NU; ++k) p.u0[(long long)k * Bsz + bq] = u[k];
             }
         } else {
             double best = -1e308;
@@ -786,7 +796,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         // closed loop (utils_class.py:266-283)
         double x[NX];
 #pragma unroll
-        for (int a = 0; a < NX; ++a) x[a] = p.rec ? p.rec[b * REC + NX * NX + NX * NU + a] : p.x0[(long long)a * Bsz + b];
+        for (int a = 0; a < NX; ++a) x[a] = p.rec ? p.rec[bq * REC + NX * NX + NX * NU + a] : p.x0[(long long)a * Bsz + bq];
         double cost = 0.0;
 #pragma unroll
         for (int a = 0; a < NX; ++a)
@@ -794,7 +804,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             for (int c = 0; c < NX; ++c) cost = __builtin_fma(x[a] * Qv(a, c), x[c], cost);
         if (p.X && writer) {
 #pragma unroll
-            for (int a = 0; a < NX; ++a) p.X[((long long)a * (p.T + 1)) * Bsz + b] = x[a];
+            for (int a = 0; a < NX; ++a) p.X[((long long)a * (p.T + 1)) * Bsz + bq] = x[a];
         }
         for (int t = 0; t < p.T; ++t) {
             double v[RB], u[NU], xn[NX];
@@ -822,11 +832,11 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             if (writer) {
                 if (p.X) {
 #pragma unroll
-                    for (int a = 0; a < NX; ++a) p.X[((long long)a * (p.T + 1) + t + 1) * Bsz + b] = xn[a];
+                    for (int a = 0; a < NX; ++a) p.X[((long long)a * (p.T + 1) + t + 1) * Bsz + bq] = xn[a];
                 }
                 if (p.U) {
 #pragma unroll
-                    for (int k = 0; k < NU; ++k) p.U[((long long)k * p.T + t) * Bsz + b] = u[k];
+                    for (int k = 0; k < NU; ++k) p.U[((long long)k * p.T + t) * Bsz + bq] = u[k];
                 }
             }
         }
