@@ -29,8 +29,8 @@ namespace lqmpc {
 // per-wavefront mapping as they are, the rollout of the larger 16-lane shapes in its low-register build (OCC = 2).
 template <int NX, int NU, int N, int MODE, int LPI>
 struct R16Build {
-    static constexpr int OCC = (LPI == 16 && N * NU > 10 && MODE == MODE_ROLLOUT) ? 2 : 1;
-    static constexpr int WAVES = (OCC == 2 || N * NU <= 10 || LPI == 64) ? 2 : 1;
+    static constexpr int OCC = (((LPI == 16 && N * NU > 10) || LPI == 64) && MODE == MODE_ROLLOUT) ? 2 : 1;
+    static constexpr int WAVES = (OCC == 2 || (N * NU <= 10 && LPI == 16)) ? 2 : 1;
 };
 
 template <int NX, int NU, int N, int MODE, int LPI>
