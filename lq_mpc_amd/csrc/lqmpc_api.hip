@@ -496,7 +496,7 @@ int lqmpc_sweep_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, i
     KParams p;
     int rc = prepare(h, c, p);
     if (rc) return rc;
-    if (use_spec(h, nx, nu, N) && use_r16(h, p, Bsz, 16384)) {
+    if (use_spec(h, nx, nu, N) && use_r16(h, p, Bsz, INT32_MAX)) {
         // one launch: condensing and W once per instance, K open-loop QPs, then the closed loop
         p.A = dA; p.B = dB; p.x0 = dx0; p.JT = dJT; p.MV = dMV; p.status = dstatus; p.iters = diters;
         if (true_per_instance) { p.At = A_true; p.Bt = B_true; }

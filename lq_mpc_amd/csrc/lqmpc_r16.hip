@@ -25,11 +25,12 @@
 
 namespace lqmpc {
 
-// Register budget: two waves per SIMD (256 registers) where the code fits them -- the n <= 10 shapes and the one-instance-
-// per-wavefront mapping as they are, the rollout of the larger 16-lane shapes in its low-register build (OCC = 2).
+// Register budget: two waves per SIMD (256 registers) -- the n <= 10 shapes as they are, the larger 16-lane shapes and the
+// one-instance-per-wavefront mapping in the low-register build (OCC = 2: rolled set-up loops, packed W, constants in LDS).
+// The fully unrolled one-wave build of those 16-lane shapes lives in lqmpc_r16_lat.hip and serves small batches.
 template <int NX, int NU, int N, int MODE, int LPI>
 struct R16Build {
-    static constexpr int OCC = (((LPI == 16 && N * NU > 10) || LPI == 64) && MODE == MODE_ROLLOUT) ? 2 : 1;
+    static constexpr int OCC = ((LPI == 16 && N * NU > 10) || LPI == 64) ? 2 : 1;
     static constexpr int WAVES = (OCC == 2 || (N * NU <= 10 && LPI == 16)) ? 2 : 1;
 };
 
@@ -80,6 +81,8 @@ static const R16Entry g_r16[] = {
     R64E(4, 2, 20),     // C4 (n = 40): one instance per wavefront (LPI = 64), same algorithm, v_readlane broadcasts
 };
 
+bool launch_r16_lat(const KParams &p, hipStream_t stream);   // lqmpc_r16_lat.hip
+
 static const R16Entry *find_r16(int nx, int nu, int N)
 {
     for (const R16Entry &e : g_r16)
@@ -94,7 +97,10 @@ bool launch_r16(const KParams &p, hipStream_t stream, const char **name)
 {
     const R16Entry *e = find_r16(p.nx, p.nu, p.N);
     if (!e) return false;
-    e->launch(p, stream);
+    // a batch of at most one wave per SIMD: the latency build where the shape has one (lqmpc_r16_lat.hip)
+    const char *env = getenv("LQMPC_R16_LAT");
+    const bool lat = e->lpi == 16 && (env ? env[0] == '1' : p.Bsz <= 4096);
+    if (!(lat && launch_r16_lat(p, stream))) e->launch(p, stream);
     if (name) *name = e->name;
     return true;
 }

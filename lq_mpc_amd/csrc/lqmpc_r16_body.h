@@ -44,7 +44,7 @@ struct R16 {
     // LDS per instance, in doubles: P | W | r | x | y | list (CS ints)
     static constexpr int oP = 0, oW = PK, oR = 2 * PK, oX = oR + VEC, oY = oX + VEC, oL = oY + VEC;
     static constexpr int oC = oL + CS / 2;            // Q | R | A_true | B_true (read from LDS when built for two waves per SIMD)
-    static constexpr int CN = 2 * NX * NX + NU * NU + NX * NU;
+    static constexpr int CN = 4 * NX * NX + NU * NU + 2 * NX * NU;   // ... | A | B | P_T (the model, for the open-loop value function)
     static constexpr int SETUP = oW + 3 * n * NX + N * NX * NX;          // condensing tables alias the W region and what follows
     static constexpr int END = oC + CN + (CN & 1);
     static constexpr int oD = (END > SETUP) ? END : SETUP;        // a dummy slot BEHIND both: predicated LDS stores go there instead of toggling exec
@@ -717,16 +717,36 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     if (MODE != MODE_ROLLOUT) {
         // open loop (utils_class.py:48-91): V_N by rolling the MODEL forward with the optimal inputs
         double Am[NX][NX], Bmm[NX][NU], Pm[NX][NX];
+        ldsd *cA = cBt + NX * NU, *cB = cA + NX * NX, *cP = cB + NX * NU;
+        if constexpr (OCC == 2) {
+            if (i == 0) {
 #pragma unroll
-        for (int a = 0; a < NX; ++a) {
+                for (int a = 0; a < NX; ++a) {
 #pragma unroll
-            for (int c = 0; c < NX; ++c) {
-                Am[a][c] = p.rec ? p.rec[bq * REC + a * NX + c] : p.A[(long long)(a * NX + c) * Bsz + bq];
-                Pm[a][c] = sh[p.so.P + a * NX + c];
+                    for (int c = 0; c < NX; ++c) {
+                        cA[a * NX + c] = p.rec ? p.rec[bq * REC + a * NX + c] : p.A[(long long)(a * NX + c) * Bsz + bq];
+                        cP[a * NX + c] = sh[p.so.P + a * NX + c];
+                    }
+#pragma unroll
+                    for (int k = 0; k < NU; ++k) cB[a * NU + k] = p.rec ? p.rec[bq * REC + NX * NX + a * NU + k] : p.B[(long long)(a * NU + k) * Bsz + bq];
+                }
             }
+            __syncthreads();
+        } else {
 #pragma unroll
-            for (int k = 0; k < NU; ++k) Bmm[a][k] = p.rec ? p.rec[bq * REC + NX * NX + a * NU + k] : p.B[(long long)(a * NU + k) * Bsz + bq];
+            for (int a = 0; a < NX; ++a) {
+#pragma unroll
+                for (int c = 0; c < NX; ++c) {
+                    Am[a][c] = p.rec ? p.rec[bq * REC + a * NX + c] : p.A[(long long)(a * NX + c) * Bsz + bq];
+                    Pm[a][c] = sh[p.so.P + a * NX + c];
+                }
+#pragma unroll
+                for (int k = 0; k < NU; ++k) Bmm[a][k] = p.rec ? p.rec[bq * REC + NX * NX + a * NU + k] : p.B[(long long)(a * NU + k) * Bsz + bq];
+            }
         }
+        auto Av = [&](int a, int c) -> double { if constexpr (OCC == 2) return cA[a * NX + c]; else return Am[a][c]; };
+        auto Bv = [&](int a, int k) -> double { if constexpr (OCC == 2) return cB[a * NU + k]; else return Bmm[a][k]; };
+        auto Pv = [&](int a, int c) -> double { if constexpr (OCC == 2) return cP[a * NX + c]; else return Pm[a][c]; };
         auto value_fn = [&](const double (&x0v)[NX], const double (&v)[RB]) -> double {
             double xs[NX], c = 0.0;
 #pragma unroll
@@ -743,9 +763,9 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 for (int a = 0; a < NX; ++a) {
                     double acc = 0.0;
 #pragma unroll
-                    for (int cc = 0; cc < NX; ++cc) acc = __builtin_fma(Am[a][cc], xs[cc], acc);
+                    for (int cc = 0; cc < NX; ++cc) acc = __builtin_fma(Av(a, cc), xs[cc], acc);
 #pragma unroll
-                    for (int k = 0; k < NU; ++k) acc = __builtin_fma(Bmm[a][k], u[k], acc);
+                    for (int k = 0; k < NU; ++k) acc = __builtin_fma(Bv(a, k), u[k], acc);
                     xn[a] = acc;
                 }
 #pragma unroll
@@ -753,7 +773,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
                 for (int a = 0; a < NX; ++a)
 #pragma unroll
-                    for (int cc = 0; cc < NX; ++cc) c = __builtin_fma(xn[a] * ((st == N - 1) ? Pm[a][cc] : Qv(a, cc)), xn[cc], c);
+                    for (int cc = 0; cc < NX; ++cc) c = __builtin_fma(xn[a] * ((st == N - 1) ? Pv(a, cc) : Qv(a, cc)), xn[cc], c);
                 if (p.has_ref) {
 #pragma unroll
                     for (int k = 0; k < NU; ++k) u[k] -= sh[p.so.uref + k * N + st];

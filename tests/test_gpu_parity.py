@@ -298,7 +298,7 @@ WG_SHAPES = [(8, 4, 30), (6, 3, 15), (16, 2, 17), (3, 2, 64), (5, 1, 33)]     # 
 
 @pytest.mark.parametrize("nx,nu,N", [(4, 2, 10), (2, 1, 10), (2, 1, 5), (2, 1, 7), (2, 1, 20), (2, 1, 30), (3, 2, 6), (1, 1, 1), (5, 3, 4), (4, 2, 20)] + WG_SHAPES)
 @pytest.mark.parametrize("warm", [0, 1])
-def test_random_problems(solver, nx, nu, N, warm):
+def test_random_problems(solver, nx, nu, N, warm, monkeypatch):
     """Unstable / badly scaled models, dense Q/R/P, asymmetric boxes, references, per-instance plants, on the
     specialised shapes (warm start on / off), on shapes only the generic kernel covers, and on the
     one-instance-per-workgroup shapes (32 < n <= 128, including stages that straddle the 16-row blocks)."""
@@ -320,23 +320,28 @@ def test_random_problems(solver, nx, nu, N, warm):
     Bt = np.ascontiguousarray(B + 0.02 * rng.standard_normal((nx, nu, Bsz)))
     A, B = np.ascontiguousarray(A), np.ascontiguousarray(B)
     umax = float(np.max(np.maximum(-lb, ub)))
-    try:
-        solver.set_options(warm_start=warm, presolve=warm)
-        g1 = solver.solve_batch(N, A, B, Q, R, P, lb, ub, x0, xr, ur)
-        g2 = solver.rollout_batch(T, N, A, B, Q, R, P, lb, ub, x0, At, Bt, xr, ur, want_traj=True)
-        k = solver.last_kernel()                                  # packed or 16-lane-row specialisation (small batches, warm start on)
-        assert ("spec" in k or "r16" in k or "r64" in k) == ((nx, nu, N) in [(4, 2, 10), (2, 1, 10), (2, 1, 5), (2, 1, 7), (2, 1, 20), (2, 1, 30), (4, 2, 20)])
-        assert ("wg" in solver.last_kernel()) == wg
-    finally:
-        solver.set_options(warm_start=-1, presolve=-1)
     r1 = orc.solve_batch(N, A, B, Q, R, P, lb, ub, x0, xr, ur)
     r2 = orc.rollout_batch(T, N, A, B, Q, R, P, lb, ub, x0, At, Bt, xr, ur, want_traj=True)
-    assert np.all(g1["status"] == 0)
-    assert rel(g1["V_N"], r1["V_N"]) < 1e-7 and u_err(g1["u_0"], r1["u_0"], umax) < RTOL
     ok = np.isfinite(r2["J_T"]) & (np.abs(r2["X"]).max(axis=(0, 1)) < 1e6)     # diverging plants amplify round-off
-    assert ok.mean() > 0.5 and np.all(g2["status"][ok] == 0)
-    assert rel(g2["J_T"][ok], r2["J_T"][ok]) < 1e-6
-    assert u_err(g2["U"][:, :3, ok], r2["U"][:, :3, ok], umax) < RTOL
+    assert ok.mean() > 0.5
+    # the two builds of the 16-lane-row kernel (one wave per SIMD for small batches, two for large): both, where both exist
+    builds = ("1", "0") if warm and (nx, nu, N) in [(4, 2, 10), (2, 1, 20)] else (None,)
+    for build in builds:
+        if build is not None: monkeypatch.setenv("LQMPC_R16_LAT", build)
+        try:
+            solver.set_options(warm_start=warm, presolve=warm)
+            g1 = solver.solve_batch(N, A, B, Q, R, P, lb, ub, x0, xr, ur)
+            g2 = solver.rollout_batch(T, N, A, B, Q, R, P, lb, ub, x0, At, Bt, xr, ur, want_traj=True)
+            k = solver.last_kernel()                                  # packed or 16-lane-row specialisation (small batches, warm start on)
+            assert ("spec" in k or "r16" in k or "r64" in k) == ((nx, nu, N) in [(4, 2, 10), (2, 1, 10), (2, 1, 5), (2, 1, 7), (2, 1, 20), (2, 1, 30), (4, 2, 20)])
+            assert ("wg" in solver.last_kernel()) == wg
+        finally:
+            solver.set_options(warm_start=-1, presolve=-1)
+        assert np.all(g1["status"] == 0)
+        assert rel(g1["V_N"], r1["V_N"]) < 1e-7 and u_err(g1["u_0"], r1["u_0"], umax) < RTOL
+        assert np.all(g2["status"][ok] == 0)
+        assert rel(g2["J_T"][ok], r2["J_T"][ok]) < 1e-6
+        assert u_err(g2["U"][:, :3, ok], r2["U"][:, :3, ok], umax) < RTOL
 
 
 def test_status_reports_iteration_cap(solver):
@@ -384,8 +389,8 @@ def test_workgroup_kernel_dispatch_and_agreement(solver):
 
 
 def test_16_lane_row_layout_whole_batch_tiered_and_hand_back(solver, monkeypatch):
-    """Rollouts of up to 16 384 instances run entirely in the 16-lane-row layout (lqmpc_r16_body.h), larger sorted ones
-    use it for their hardest instances (forced here with LQMPC_R16=0 + LQMPC_NWIDE).  References, an off-centre box and
+    """Rollouts of the shapes it serves run entirely in the 16-lane-row layout (lqmpc_r16_body.h; both of its builds,
+    LQMPC_R16_LAT=1/0); the packed family's tiered kernel uses it for its hardest instances (LQMPC_R16=0 + LQMPC_NWIDE).  References, an off-centre box and
     per-instance plants go through it; with its iteration cap forced to 1 it hands the constrained instances back
     (status 3 internally) and the packed kernel's second pass must restore every one."""
     rng = np.random.default_rng(7)
@@ -399,9 +404,10 @@ def test_16_lane_row_layout_whole_batch_tiered_and_hand_back(solver, monkeypatch
     ref = orc.rollout_batch(T, *a, b["x0"], At, Bt, xr, ur, want_traj=True)
     try:
         solver.set_options(order=1)
-        for layout, cap, nwide, name in ((None, None, None, "r16"), (None, "1", None, "r16"), ("0", None, "1024", "tiered"),
-                                         ("0", "1", "1024", "tiered"), ("0", None, "2048", "tiered")):
-            for key, val in (("LQMPC_R16", layout), ("LQMPC_R16_MAXIT", cap), ("LQMPC_NWIDE", nwide)):
+        for layout, cap, nwide, lat, name in ((None, None, None, "1", "r16"), (None, "1", None, "1", "r16"), (None, None, None, "0", "r16"),
+                                              (None, "1", None, "0", "r16"), ("0", None, "1024", None, "tiered"),
+                                              ("0", "1", "1024", None, "tiered"), ("0", None, "2048", None, "tiered")):
+            for key, val in (("LQMPC_R16", layout), ("LQMPC_R16_MAXIT", cap), ("LQMPC_NWIDE", nwide), ("LQMPC_R16_LAT", lat)):
                 if val is None: monkeypatch.delenv(key, raising=False)
                 else: monkeypatch.setenv(key, val)
             g = solver.rollout_batch(T, *a, b["x0"], At, Bt, xr, ur, want_traj=True)
@@ -421,15 +427,17 @@ def test_sweep_batch_is_max_vn_plus_rollout(solver, monkeypatch):
         x0s = np.ascontiguousarray(1.5 * b["x0"][:, :6])
         mv = orc.max_vn_batch(*a, x0s)
         jt = orc.rollout_batch(12, *a, b["x0"], b["A_true"], b["B_true"])["J_T"]
-        for cap in ((None, "1") if fused else (None,)):
-            if cap is None: monkeypatch.delenv("LQMPC_R16_MAXIT", raising=False)
-            else: monkeypatch.setenv("LQMPC_R16_MAXIT", cap)
+        for cap, lat in (((None, "1"), ("1", "1"), (None, "0"), ("1", "0")) if fused else ((None, None),)):
+            for key, val in (("LQMPC_R16_MAXIT", cap), ("LQMPC_R16_LAT", lat)):
+                if val is None: monkeypatch.delenv(key, raising=False)
+                else: monkeypatch.setenv(key, val)
             g = solver.sweep_batch(12, *a, b["x0"], x0s, b["A_true"], b["B_true"])
             assert ("r16" in solver.last_kernel()) == fused
             assert np.all(g["status"] == 0)
             assert rel(g["M_V"], mv) < TIGHT and rel(g["J_T"], jt) < TIGHT
-            if cap is None: g0 = g
+            if cap is None and lat != "0": g0 = g
         monkeypatch.delenv("LQMPC_R16_MAXIT", raising=False)
+        monkeypatch.delenv("LQMPC_R16_LAT", raising=False)
         m2 = solver.max_vn_batch(*a, x0s)
         r2 = solver.rollout_batch(12, *a, b["x0"], b["A_true"], b["B_true"])
         assert rel(g0["M_V"], m2["M_V"]) < 1e-12 and rel(g0["J_T"], r2["J_T"]) < 1e-12
