@@ -138,11 +138,11 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     constexpr bool PACKED = (OCC == 2);
     using C = R16<NX, NU, N, LPI, PACKED>;
     constexpr int CS = C::CS;
-    // Unrolling of the three horizon-length loops of the condensing.  Fully unrolled they are fastest (N <= 10: C2, C3, 3-5 %)
-    // but the scheduler then hoists every LDS load to the top and spills (128 VGPRs at C3, 900 at N = 20); partly rolled
-    // the longer horizons compile without a single spill and run faster than with them (C4: 25.7 ms against 45.6 ms).
+    // Unrolling of the horizon-length loop of the Fq rows (the powers of A and the diagonal sums are run-time loops with
+    // a few instructions per step).  Fully unrolled it is fastest for N <= 10, but further the scheduler hoists every LDS
+    // load to the top and spills; partly rolled the longer horizons compile without a spill.
     constexpr bool UNROLL = (N <= 10) && OCC == 1;
-    constexpr int UNR_CHAIN = UNROLL ? N : 1, UNR_SUFFIX = UNROLL ? N : 4, UNR_FQ = UNROLL ? N : 2;
+    constexpr int UNR_FQ = UNROLL ? N : 2;
     constexpr int n = C::n, RB = C::RB, LDW = C::LDW;
     constexpr int REC = NX * NX + NX * NU + NX;
     const int lane = threadIdx.x, q = lane / LPI, i = lane % LPI;
@@ -185,70 +185,41 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     {
         RPROF_START;
         ldsd *MA = Wp, *PM = MA + n * NX, *QM = PM + n * NX, *AP = QM + n * NX;
-        double A[NX][NX], Bm[NX][NU];
-#pragma unroll
-        for (int a = 0; a < NX; ++a) {
-#pragma unroll
-            for (int c = 0; c < NX; ++c) A[a][c] = p.rec ? p.rec[b * REC + a * NX + c] : p.A[(long long)(a * NX + c) * Bsz + b];
-#pragma unroll
-            for (int k = 0; k < NU; ++k) Bm[a][k] = p.rec ? p.rec[b * REC + NX * NX + a * NU + k] : p.B[(long long)(a * NU + k) * Bsz + b];
-        }
+        static_assert(NX * NX <= LPI, "one lane per element of a power of A");
+        auto gA = [&](int a, int c) -> double { return p.rec ? p.rec[b * REC + a * NX + c] : p.A[(long long)(a * NX + c) * Bsz + b]; };
+        auto gB = [&](int a, int k) -> double { return p.rec ? p.rec[b * REC + NX * NX + a * NU + k] : p.B[(long long)(a * NU + k) * Bsz + b]; };
         double ma[RB][NX];
+        {   // the powers of A, one element per lane: A^(m+1)(ea, ek) = A(ea, :) . A^m(:, ek), through the table itself
+            const bool el = i < NX * NX;
+            const int ea = el ? i / NX : 0, ek = el ? i % NX : 0;
+            double Ar[NX];
 #pragma unroll
-        for (int s = 0; s < RB; ++s)
+            for (int c = 0; c < NX; ++c) Ar[c] = gA(ea, c);
+            if (el) AP[i] = gA(ea, ek);
+#pragma unroll 1
+            for (int m = 1; m < N; ++m) {
+                __syncthreads();
+                double t = 0.0;
 #pragma unroll
-            for (int a = 0; a < NX; ++a) ma[s][a] = 0.0;
-        {   // every lane runs the chains M_m = A^m B and A^(m+1); rows capture their column, lane e % 16 stores element e of A^(m+1)
-            double Mc[NX][NU], Ap[NX][NX];
-#pragma unroll
-            for (int a = 0; a < NX; ++a) {
-#pragma unroll
-                for (int k = 0; k < NU; ++k) Mc[a][k] = Bm[a][k];
-#pragma unroll
-                for (int c = 0; c < NX; ++c) Ap[a][c] = A[a][c];
+                for (int c = 0; c < NX; ++c) t = __builtin_fma(Ar[c], AP[(m - 1) * NX * NX + c * NX + ek], t);
+                if (el) AP[m * NX * NX + i] = t;
             }
-#pragma unroll UNR_CHAIN                         // nothing below is indexed by m at compile time
-            for (int m = 0; m < N; ++m) {
-                if (m > 0) {
-                    double T[NX][NU], T2[NX][NX];
+            __syncthreads();
+            // my rows' columns of M_a = A^a B
 #pragma unroll
-                    for (int a = 0; a < NX; ++a) {
+            for (int s = 0; s < RB; ++s) {
+                const int mm = vrow[s] ? N - 1 - rw[s] / NU : 0, uk = rw[s] % NU;
+                const int base = (mm > 0 ? mm - 1 : 0) * NX * NX;
+                double bk[NX];
 #pragma unroll
-                        for (int k = 0; k < NU; ++k) {
-                            double t = 0.0;
+                for (int a = 0; a < NX; ++a) bk[a] = gB(a, uk);
 #pragma unroll
-                            for (int c = 0; c < NX; ++c) t = __builtin_fma(A[a][c], Mc[c][k], t);
-                            T[a][k] = t;
-                        }
+                for (int a = 0; a < NX; ++a) {
+                    double t = 0.0;
 #pragma unroll
-                        for (int k = 0; k < NX; ++k) {
-                            double t = 0.0;
-#pragma unroll
-                            for (int c = 0; c < NX; ++c) t = __builtin_fma(A[a][c], Ap[c][k], t);
-                            T2[a][k] = t;
-                        }
-                    }
-#pragma unroll
-                    for (int a = 0; a < NX; ++a) {
-#pragma unroll
-                        for (int k = 0; k < NU; ++k) Mc[a][k] = T[a][k];
-#pragma unroll
-                        for (int k = 0; k < NX; ++k) Ap[a][k] = T2[a][k];
-                    }
+                    for (int c = 0; c < NX; ++c) t = __builtin_fma(AP[base + a * NX + c], bk[c], t);
+                    ma[s][a] = vrow[s] ? (mm > 0 ? t : bk[a]) : 0.0;
                 }
-#pragma unroll
-                for (int s = 0; s < RB; ++s) {
-                    const bool mine = vrow[s] && (rw[s] / NU == N - 1 - m);
-#pragma unroll
-                    for (int k = 0; k < NU; ++k)
-#pragma unroll
-                        for (int a = 0; a < NX; ++a) ma[s][a] = (mine && rw[s] % NU == k) ? Mc[a][k] : ma[s][a];
-                }
-                if (i == 0) {                                            // one lane stores A^(m+1) (one exec toggle per power)
-#pragma unroll
-                    for (int e = 0; e < NX * NX; ++e) AP[m * NX * NX + e] = Ap[e / NX][e % NX];
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
         RPROF(0);
@@ -295,45 +266,32 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         }
         __syncthreads();
         RPROF(1);
-        // H = suffix sums of T along the stage diagonals; P = 2 (H + Rbar)
-        double Wr[RB][n];
-#pragma unroll
-        for (int s = 0; s < RB; ++s) {
-#pragma unroll
-            for (int j = 0; j < n; ++j) {
+        // H = suffix sums of T along the stage diagonals, in place: a lane walks whole diagonals from their far end
+        // (chain c starts at (i0, j0) = (c / NU, c % NU), j0 <= i0, and steps by (NU, NU)); P = 2 (H + Rbar)
+#pragma unroll 1
+        for (int c = i; c < n * NU; c += LPI) {
+            const int i0 = c / NU, j0 = c % NU;
+            if (j0 <= i0) {
+                const double radd = (i0 < NU) ? sh[p.so.R + i0 * NU + j0] : 0.0;
                 double acc = 0.0;
-                if (j <= LPI * s + LPI - 1) {
-                    const int dcnt = (n - LPI * s + NU - 1) / NU;        // terms of the longest diagonal of this slot (constant after unrolling s)
-#pragma unroll UNR_SUFFIX                                // bounds how far ahead the loads can be hoisted
-                    for (int d = 0; d < (dcnt < N ? dcnt : N); ++d) {
-                        const bool in = vrow[s] && j <= rw[s] && rw[s] + d * NU < n;
-                        const double t = Pp[in ? ad2(rw[s] + d * NU, j + d * NU) : 0];
-                        acc += in ? t : 0.0;
-                    }
+#pragma unroll 1
+                for (int s2 = (n - 1 - i0) / NU; s2 >= 0; --s2) {
+                    const int r = i0 + s2 * NU, cc = j0 + s2 * NU;
+                    const int idx = PACKED ? r * (r + 1) / 2 + cc : r * LDW + cc;
+                    acc += Pp[idx];
+                    Pp[idx] = 2.0 * (acc + radd);
                 }
-                Wr[s][j] = acc;
-                if (j % 2 == 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int s = 0; s < RB; ++s) {
-            const int bi = rw[s] / NU, ui = rw[s] % NU;
-#pragma unroll
-            for (int j = 0; j < n; ++j) {
-                if (j > LPI * s + LPI - 1) continue;
-                const double val = 2.0 * (Wr[s][j] + ((j / NU == bi) ? sh[p.so.R + ui * NU + (j % NU)] : 0.0));
-                Wr[s][j] = val;
-                Pp[(vrow[s] && j <= rw[s]) ? ad(rw[s], tri[s], j) : DUMMY] = val;
-            }
-        }
-        __syncthreads();
+        double Wr[RB][n];                       // my rows, both triangles
 #pragma unroll
         for (int s = 0; s < RB; ++s)
 #pragma unroll
             for (int j = 0; j < n; ++j) {
-                const double up = Pp[(vrow[s] && j > rw[s]) ? ad2(j, rw[s]) : 0];
-                Wr[s][j] = vrow[s] ? ((j > rw[s]) ? up : Wr[s][j]) : 0.0;
+                const int idx = PACKED ? ad(rw[s], tri[s], j) : ((j <= rw[s]) ? rw[s] * LDW + j : j * LDW + rw[s]);
+                const double t = Pp[vrow[s] ? idx : 0];
+                Wr[s][j] = vrow[s] ? t : 0.0;
                 if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
             }
         __syncthreads();
