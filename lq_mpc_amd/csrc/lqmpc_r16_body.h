@@ -12,6 +12,8 @@ using wg::ldsi;
 using wg::rowb;
 using wg::fmac_rowb;
 using wg::fmac_rowb_self;
+using wg::fmac_rowb4;
+using wg::fmac_rowb_self4;
 using wg::dpp_settle;
 
 #ifdef LQMPC_R16_PROF
@@ -84,6 +86,25 @@ __device__ __forceinline__ void ifmac_self(double &acc, double y, int k)
     if constexpr (LPI == 16) fmac_rowb_self(acc, y, k);
     else acc = __builtin_fma(wg::rdlane(acc, k), y, acc);
 }
+// four of each with one lane and one multiplier
+template <int LPI>
+__device__ __forceinline__ void ifmac4(double *acc, const double *x, double y, int k)
+{
+    if constexpr (LPI == 16) fmac_rowb4(acc[0], acc[1], acc[2], acc[3], x[0], x[1], x[2], x[3], y, k);
+    else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = __builtin_fma(wg::rdlane(x[e], k), y, acc[e]);
+    }
+}
+template <int LPI>
+__device__ __forceinline__ void ifmac_self4(double *acc, double y, int k)
+{
+    if constexpr (LPI == 16) fmac_rowb_self4(acc[0], acc[1], acc[2], acc[3], y, k);
+    else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = __builtin_fma(wg::rdlane(acc[e], k), y, acc[e]);
+    }
+}
 template <int LPI>
 __device__ __forceinline__ void isettle(double &x)
 {
@@ -109,12 +130,22 @@ __device__ __forceinline__ void gj_invert_step(double (&M)[RB][n], const int (&r
         M[s][K] = isk ? 1.0 : 0.0;
     }
 #pragma unroll
-    for (int j = 0; j < n; ++j) {
+    for (int j0 = 0; j0 < n; j0 += 4) {
+        if (j0 + 4 <= n && (K < j0 || K >= j0 + 4)) {                 // a whole group of four columns away from the pivot's
 #pragma unroll
-        for (int s = 0; s < RB; ++s)
-            if (s != sk) ifmac<LPI>(M[s][j], M[sk][j], g[s], lk);     // the pivot row's own slot last: it rescales the row the others read
-        if (j == K) ifmac<LPI>(M[sk][j], M[sk][j], g[sk], lk);       // (column K was written just above: DPP wait states)
-        else ifmac_self<LPI>(M[sk][j], g[sk], lk);
+            for (int s = 0; s < RB; ++s)
+                if (s != sk) ifmac4<LPI>(&M[s][j0], &M[sk][j0], g[s], lk);   // the pivot row's own slot last: it rescales the row the others read
+            ifmac_self4<LPI>(&M[sk][j0], g[sk], lk);
+        } else {
+#pragma unroll
+            for (int j = j0; j < (j0 + 4 < n ? j0 + 4 : n); ++j) {
+#pragma unroll
+                for (int s = 0; s < RB; ++s)
+                    if (s != sk) ifmac<LPI>(M[s][j], M[sk][j], g[s], lk);
+                if (j == K) ifmac<LPI>(M[sk][j], M[sk][j], g[sk], lk);       // (column K was written just above: DPP wait states)
+                else ifmac_self<LPI>(M[sk][j], g[sk], lk);
+            }
+        }
     }
 }
 template <int RB, int n, int LPI, int... K>
@@ -419,8 +450,11 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
             for (int s = 0; s < RB; ++s) {
                 const double nw = -Wr[s][j];
+                if constexpr (NX == 4) ifmac4<LPI>(&G[s][0], &Facc[sj][0], nw, lj);
+                else {
 #pragma unroll
-                for (int a = 0; a < NX; ++a) ifmac<LPI>(G[s][a], Facc[sj][a], nw, lj);
+                    for (int a = 0; a < NX; ++a) ifmac<LPI>(G[s][a], Facc[sj][a], nw, lj);
+                }
                 if (has_lin) ifmac<LPI>(vr[s], qr[sj], nw, lj);
             }
         });
@@ -591,9 +625,12 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
                         for (int jg = 0; jg < CS / 4; ++jg) {    // columns in groups of four: one uniform test per group
                             if (4 * jg + 3 > k && 4 * jg < cw) {  // first half static, second uniform
+                                if (4 * jg > k) ifmac_self4<LPI>(&S[4 * jg], g, k);
+                                else {
 #pragma unroll
-                                for (int j = 4 * jg; j < 4 * jg + 4; ++j)
-                                    if (j > k) ifmac_self<LPI>(S[j], g, k);
+                                    for (int j = 4 * jg; j < 4 * jg + 4; ++j)
+                                        if (j > k) ifmac_self<LPI>(S[j], g, k);
+                                }
                             }
                         }
                         ifmac_self<LPI>(rhs, g, k);
