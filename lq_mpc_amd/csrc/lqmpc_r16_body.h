@@ -45,8 +45,8 @@ struct R16 {
     static constexpr int VEC = LPI * RB;
     // LDS per instance, in doubles: P | W | r | x | y | list (CS ints)
     static constexpr int oP = 0, oW = PK, oR = 2 * PK, oX = oR + VEC, oY = oX + VEC, oL = oY + VEC;
-    static constexpr int oC = oL + CS / 2;            // Q | R | A_true | B_true (read from LDS when built for two waves per SIMD)
-    static constexpr int CN = 4 * NX * NX + NU * NU + 2 * NX * NU;   // ... | A | B | P_T (the model, for the open-loop value function)
+    static constexpr int oC = oL + CS / 2;            // Q | R | A | B | P_T: the open-loop value function's constants (read from LDS
+    static constexpr int CN = 3 * NX * NX + NU * NU + NX * NU;   // when built for two waves per SIMD)
     static constexpr int SETUP = oW + 3 * n * NX + N * NX * NX;          // condensing tables alias the W region and what follows
     static constexpr int END = oC + CN + (CN & 1);
     static constexpr int oD = (END > SETUP) ? END : SETUP;        // a dummy slot BEHIND both: predicated LDS stores go there instead of toggling exec
@@ -491,20 +491,18 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         h[s] = vrow[s] ? 0.5 * (sh[p.so.ub + k] - sh[p.so.lb + k]) : 1.0;
         ctr[s] = vrow[s] ? 0.5 * (sh[p.so.ub + k] + sh[p.so.lb + k]) : 0.0;
     }
-    // stage weights once: inside the step loop they would be vector loads per step
-    double Qm[NX][NX], Rm[NU][NU], Atm[NX][NX], Btm[NX][NU];
-    ldsd *cQ = L + C::oC, *cR = cQ + NX * NX, *cAt = cR + NU * NU, *cBt = cAt + NX * NX;
-    if constexpr (OCC == 2) {
+    // stage weights of the open-loop value function once (the closed loop keeps its rows of them per lane, see below)
+    double Qm[NX][NX], Rm[NU][NU];
+    ldsd *cQ = L + C::oC, *cR = cQ + NX * NX;
+    if constexpr (MODE == MODE_ROLLOUT) {
+    } else if constexpr (OCC == 2) {
         if (i == 0) {
 #pragma unroll
             for (int a = 0; a < NX; ++a) {
 #pragma unroll
                 for (int c = 0; c < NX; ++c) {
                     cQ[a * NX + c] = sh[p.so.Q + a * NX + c];
-                    cAt[a * NX + c] = p.true_per_instance ? p.At[(long long)(a * NX + c) * Bsz + bq] : sh[p.so.At + a * NX + c];
                 }
-#pragma unroll
-                for (int k = 0; k < NU; ++k) cBt[a * NU + k] = p.true_per_instance ? p.Bt[(long long)(a * NU + k) * Bsz + bq] : sh[p.so.Bt + a * NU + k];
             }
 #pragma unroll
             for (int k = 0; k < NU; ++k)
@@ -516,15 +514,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
         for (int a = 0; a < NX; ++a) {
 #pragma unroll
-            for (int c = 0; c < NX; ++c) {
-                Qm[a][c] = sh[p.so.Q + a * NX + c];
-                if (MODE == MODE_ROLLOUT || MODE == MODE_SWEEP)
-                    Atm[a][c] = p.true_per_instance ? p.At[(long long)(a * NX + c) * Bsz + bq] : sh[p.so.At + a * NX + c];
-            }
-            if (MODE == MODE_ROLLOUT || MODE == MODE_SWEEP) {
-#pragma unroll
-                for (int k = 0; k < NU; ++k) Btm[a][k] = p.true_per_instance ? p.Bt[(long long)(a * NU + k) * Bsz + bq] : sh[p.so.Bt + a * NU + k];
-            }
+            for (int c = 0; c < NX; ++c) Qm[a][c] = sh[p.so.Q + a * NX + c];
         }
 #pragma unroll
         for (int k = 0; k < NU; ++k)
@@ -533,8 +523,6 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     }
     auto Qv = [&](int a, int c) -> double { if constexpr (OCC == 2) return cQ[a * NX + c]; else return Qm[a][c]; };
     auto Rv = [&](int k, int j) -> double { if constexpr (OCC == 2) return cR[k * NU + j]; else return Rm[k][j]; };
-    auto Atv = [&](int a, int c) -> double { if constexpr (OCC == 2) return cAt[a * NX + c]; else return Atm[a][c]; };
-    auto Btv = [&](int a, int k) -> double { if constexpr (OCC == 2) return cBt[a * NU + k]; else return Btm[a][k]; };
     const bool writer = valid && i == 0;
     mask_t pL = 0, pU = 0;                  // active set of the previous step (row-uniform bit masks)
     int iters = 0, status = 0;
@@ -712,7 +700,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     if (MODE != MODE_ROLLOUT) {
         // open loop (utils_class.py:48-91): V_N by rolling the MODEL forward with the optimal inputs
         double Am[NX][NX], Bmm[NX][NU], Pm[NX][NX];
-        ldsd *cA = cBt + NX * NU, *cB = cA + NX * NX, *cP = cB + NX * NU;
+        ldsd *cA = cR + NU * NU, *cB = cA + NX * NX, *cP = cB + NX * NU;
         if constexpr (OCC == 2) {
             if (i == 0) {
 #pragma unroll
@@ -808,15 +796,52 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     }
     if (MODE == MODE_ROLLOUT || MODE == MODE_SWEEP) {
         pL = 0; pU = 0;
-        // closed loop (utils_class.py:266-283)
+        // closed loop (utils_class.py:266-283).  The plant and the stage cost are spread over the lanes of the instance: lane
+        // a < NX owns row a of [A_true B_true] and of Q (its state is broadcast to the others each step), lane k < NU owns row k
+        // of R; the partial costs are summed over the lanes once, after the last step.
         double x[NX];
 #pragma unroll
         for (int a = 0; a < NX; ++a) x[a] = p.rec ? p.rec[bq * REC + NX * NX + NX * NU + a] : p.x0[(long long)a * Bsz + bq];
-        double cost = 0.0;
+        int ia = i < NX ? i : 0, ik = i < NU ? i : 0;
+        asm volatile("" : "+v"(ia), "+v"(ik));          // (opaque: or these loads are issued at the top and their results spilled across the set-up)
+        double Qr_[NX], Ar_[NX], Br_[NU], Rr_[NU];
 #pragma unroll
-        for (int a = 0; a < NX; ++a)
+        for (int c = 0; c < NX; ++c) {
+            Qr_[c] = sh[p.so.Q + ia * NX + c];
+            Ar_[c] = p.true_per_instance ? p.At[(long long)(ia * NX + c) * Bsz + bq] : sh[p.so.At + ia * NX + c];
+        }
 #pragma unroll
-            for (int c = 0; c < NX; ++c) cost = __builtin_fma(x[a] * Qv(a, c), x[c], cost);
+        for (int k = 0; k < NU; ++k) {
+            Br_[k] = p.true_per_instance ? p.Bt[(long long)(ia * NU + k) * Bsz + bq] : sh[p.so.Bt + ia * NU + k];
+            Rr_[k] = sh[p.so.R + ik * NU + k];
+        }
+        // built for two waves per SIMD: my rows live in the LDS constants region (the open-loop part is done with it), read per step
+        constexpr int RW = 2 * NX + 2 * NU;
+        static_assert((NX > NU ? NX : NU) * RW <= C::CN + (C::CN & 1), "the per-lane rows fit the constants region");
+        ldsd *myc = L + C::oC + ((i < NX || i < NU) ? i : 0) * RW;
+        if constexpr (OCC == 2) {
+            __syncthreads();
+            if (i < NX || i < NU) {
+#pragma unroll
+                for (int c = 0; c < NX; ++c) { myc[c] = Ar_[c]; myc[NX + NU + c] = Qr_[c]; }
+#pragma unroll
+                for (int k = 0; k < NU; ++k) { myc[NX + k] = Br_[k]; myc[2 * NX + NU + k] = Rr_[k]; }
+            }
+            __syncthreads();
+        }
+        auto Ar = [&](int c) -> double { if constexpr (OCC == 2) return myc[c]; else return Ar_[c]; };
+        auto Br = [&](int k) -> double { if constexpr (OCC == 2) return myc[NX + k]; else return Br_[k]; };
+        auto Qr = [&](int c) -> double { if constexpr (OCC == 2) return myc[NX + NU + c]; else return Qr_[c]; };
+        auto Rr = [&](int k) -> double { if constexpr (OCC == 2) return myc[2 * NX + NU + k]; else return Rr_[k]; };
+        double costx, costu = 0.0;
+        {
+            double xm = x[0], qx = 0.0;
+#pragma unroll
+            for (int a = 1; a < NX; ++a) xm = (i == a) ? x[a] : xm;
+#pragma unroll
+            for (int c = 0; c < NX; ++c) qx = __builtin_fma(Qr(c), x[c], qx);
+            costx = xm * qx;
+        }
         if (p.X && writer) {
 #pragma unroll
             for (int a = 0; a < NX; ++a) p.X[((long long)a * (p.T + 1)) * Bsz + bq] = x[a];
@@ -824,26 +849,23 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         for (int t = 0; t < p.T; ++t) {
             double v[RB], u[NU], xn[NX];
             qp(x, v);
+            const double um = fmin(fmax(v[0], -h[0]), h[0]) + ctr[0];     // the input of my first row: u_i in lane i < NU
             stage_input(v, 0, u);
+            double xm = 0.0, qx = 0.0, ru = 0.0;
 #pragma unroll
-            for (int a = 0; a < NX; ++a) {
-                double acc = 0.0;
+            for (int c = 0; c < NX; ++c) xm = __builtin_fma(Ar(c), x[c], xm);
 #pragma unroll
-                for (int c = 0; c < NX; ++c) acc = __builtin_fma(Atv(a, c), x[c], acc);
+            for (int k = 0; k < NU; ++k) xm = __builtin_fma(Br(k), u[k], xm);
 #pragma unroll
-                for (int k = 0; k < NU; ++k) acc = __builtin_fma(Btv(a, k), u[k], acc);
-                xn[a] = acc;
-            }
+            for (int a = 0; a < NX; ++a) xn[a] = ibcast<LPI>(xm, a);
 #pragma unroll
             for (int a = 0; a < NX; ++a) x[a] = xn[a];
 #pragma unroll
-            for (int a = 0; a < NX; ++a)
+            for (int c = 0; c < NX; ++c) qx = __builtin_fma(Qr(c), xn[c], qx);
+            costx = __builtin_fma(xm, qx, costx);
 #pragma unroll
-                for (int c = 0; c < NX; ++c) cost = __builtin_fma(xn[a] * Qv(a, c), xn[c], cost);
-#pragma unroll
-            for (int k = 0; k < NU; ++k)
-#pragma unroll
-                for (int j = 0; j < NU; ++j) cost = __builtin_fma(u[k] * Rv(k, j), u[j], cost);
+            for (int j = 0; j < NU; ++j) ru = __builtin_fma(Rr(j), u[j], ru);
+            costu = __builtin_fma(um, ru, costu);
             if (writer) {
                 if (p.X) {
 #pragma unroll
@@ -855,6 +877,11 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 }
             }
         }
+        double cost = 0.0;
+#pragma unroll
+        for (int a = 0; a < NX; ++a) cost += ibcast<LPI>(costx, a);
+#pragma unroll
+        for (int k = 0; k < NU; ++k) cost += ibcast<LPI>(costu, k);
         RPROF(7);
         if (writer) p.JT[b] = cost;
     }
