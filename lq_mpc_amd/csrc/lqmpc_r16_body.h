@@ -274,7 +274,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             }
         }
         __syncthreads();
-        // T(i, j), j <= i, into the packed P region
+        // T(i, j), j <= i, into the P region: a row slot computes its own diagonal block and, transposed, the blocks below it
 #pragma unroll
         for (int s = 0; s < RB; ++s) {
             const bool nxt = vrow[s] && rw[s] + NU < n;
@@ -283,7 +283,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             for (int a = 0; a < NX; ++a) man[a] = nxt ? MA[(rw[s] + NU) * NX + a] : 0.0;
 #pragma unroll
             for (int j = 0; j < n; ++j) {
-                if (j > LPI * s + LPI - 1) continue;                   // static: no row of this slot reaches column j
+                if (j < LPI * s) continue;                             // static: the slot of row j computes these, transposed (T is symmetric)
                 double t = 0.0;
 #pragma unroll
                 for (int a = 0; a < NX; ++a) t = __builtin_fma(ma[s][a], PM[j * NX + a], t);
@@ -291,7 +291,8 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
                     for (int a = 0; a < NX; ++a) t = __builtin_fma(man[a], QM[(j + NU) * NX + a] - PM[(j + NU) * NX + a], t);
                 }
-                Pp[(vrow[s] && j <= rw[s]) ? ad(rw[s], tri[s], j) : DUMMY] = t;
+                if (j < LPI * s + LPI) Pp[(vrow[s] && j <= rw[s]) ? ad(rw[s], tri[s], j) : DUMMY] = t;
+                else Pp[vrow[s] ? (PACKED ? j * (j + 1) / 2 + rw[s] : j * LDW + rw[s]) : DUMMY] = t;   // (j, my row): a later slot's row
                 if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // straight-line code: keep the loads near their use
             }
         }
