@@ -88,7 +88,7 @@ typedef struct lqmpc_options {
                           interior is finished there, exactly.  -1 auto (= on), 0 off, 1 on.  Specialised kernels only; the generic kernel ignores it.  (default -1) */
     int32_t order;     /* processing order of a rollout batch.  1: a probe launch computes a difficulty key per instance
                           (largest stage gradient of the free response over the horizon, in units of what one input
-                          can counter), the batch is radix-sorted by it and the rollout walks it hardest-first, so the
+                          can counter), the batch is bucket-sorted by its logarithm and the rollout walks it hardest-first, so the
                           instances that share a wavefront leave the constrained regime together; results are written
                           back to their original positions and do not depend on the order.  0: natural order.
                           -1 auto (1 for specialised rollouts with presolve, T >= 4 and Bsz >= 1024).  (default -1) */

@@ -30,7 +30,8 @@ struct KParams {
     double *u0, *VN, *JT, *X, *U, *MV;    // outputs (device; X, U may be null)
     int *status, *iters;                  // may be null
     const int *perm;                      // processing order (slot -> instance), null = natural order
-    double *key;                          // MODE_PROBE output: difficulty key per instance
+    double *key;                          // MODE_PROBE output per instance: (difficulty bucket, position inside the bucket), two ints
+    int *hist;                            // MODE_PROBE: instances per difficulty bucket (ORDER_BUCKETS counters, zeroed by the host)
     double *stage;                        // MODE_PROBE output: instance-major [A|B|x0] records (null: none)
     const double *rec;                    // input records staged by the probe (null: read A, B, x0 directly)
     long long nwide;                      // tiered rollout: the first nwide slots of the order get a wavefront each
@@ -38,6 +39,8 @@ struct KParams {
     const int *count_dev;                 // packed kernel as the fallback pass: number of slots to process, on the device
     int r16_maxit;                        // active-set iteration cap of the 16-lane-row layout before it hands an instance back
 };
+
+constexpr int ORDER_BUCKETS = 4096;          // difficulty buckets of the ordering: 128 per binade of the key over [2^-8, 2^24)
 
 // ---- fp64 reciprocal / reciprocal square root: hardware seed + Newton steps ----
 // v_rcp_f64 / v_rsq_f64 give a seed good to ~2^-26 or better; two Newton steps reach ~1 ulp

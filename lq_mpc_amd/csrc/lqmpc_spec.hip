@@ -1223,8 +1223,66 @@ __global__ void __launch_bounds__(64) lqmpc_probe_kernel(KParams p)
         }
     }
     const double kk = (key == key) ? key : 1e300;
-    ((unsigned *)p.key)[b] = (unsigned)__double2hiint(kk);       // upper half: same order for positive values
-    if (p.fail_list) p.fail_list[b] = (int)b;                       // the identity permutation the sort starts from (borrowed field)
+    // The order only has to group similar instances, hardest first: a bucket sort on the logarithm of the key (exponent and
+    // seven mantissa bits of the fp64: 128 buckets per binade, clamped to [2^-8, 2^24)).  Each wavefront reserves its
+    // positions inside a bucket with one atomic per distinct bucket it holds; lqmpc_order_scatter_kernel turns
+    // (bucket, position) into the slot of the instance.
+    const int raw = (int)((unsigned)__double2hiint(kk) >> 13) - ((1023 - 8) << 7);
+    const int bucket = raw < 0 ? 0 : (raw > ORDER_BUCKETS - 1 ? ORDER_BUCKETS - 1 : raw);
+    const int lane = threadIdx.x;
+    int my_leader = lane, rank = 0, cnt = 0;           // the lanes of my bucket: first of them, my rank among them, their number
+    unsigned long long todo = __ballot(1);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lb = __shfl(bucket, leader);
+        const unsigned long long same = __ballot(bucket == lb);
+        if (bucket == lb) {
+            my_leader = leader;
+            rank = __popcll(same & ((1ull << lane) - 1ull));
+            cnt = __popcll(same);
+        }
+        todo &= ~same;
+    }
+    int base = 0;
+    if (lane == my_leader) base = atomicAdd(&p.hist[bucket], cnt);     // all the wave's reservations in flight at once
+    base = __shfl(base, my_leader);
+    ((int2 *)p.key)[b] = make_int2(bucket, base + rank);
+}
+
+// slot of an instance = instances in harder buckets + its position inside its bucket.  Every block scans the bucket counts
+// itself (4096 counters: cheaper than another launch) and places 1024 instances.
+__global__ void __launch_bounds__(256) lqmpc_order_scatter_kernel(const int2 *where, const int *hist, int *perm, long long Bsz)
+{
+    __shared__ int base[ORDER_BUCKETS];
+    __shared__ int part[256];
+    constexpr int PER = ORDER_BUCKETS / 256;
+    const int t = threadIdx.x;
+    int above_in_chunk[PER], sum = 0;
+#pragma unroll
+    for (int e = PER - 1; e >= 0; --e) { above_in_chunk[e] = sum; sum += hist[PER * t + e]; }
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d *= 2) {                       // inclusive suffix sums over the threads' chunks
+        const int v = part[t] + (t + d < 256 ? part[t + d] : 0);
+        __syncthreads();
+        part[t] = v;
+        __syncthreads();
+    }
+    const int above = part[t] - sum;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) base[PER * t + e] = above + above_in_chunk[e];
+    __syncthreads();
+    const long long i0 = (long long)blockIdx.x * 1024;
+    for (long long i = i0 + t; i < i0 + 1024 && i < Bsz; i += 256) {
+        const int2 w = where[i];
+        perm[base[w.x] + w.y] = (int)i;
+    }
+}
+
+void launch_order_scatter(const KParams &p, int *perm, hipStream_t stream)
+{
+    hipLaunchKernelGGL(lqmpc_order_scatter_kernel, dim3((unsigned)((p.Bsz + 1023) / 1024)), dim3(256), 0, stream,
+                       (const int2 *)p.key, (const int *)p.hist, perm, (long long)p.Bsz);
 }
 
 // ---------------- registry of built specialisations ----------------
