@@ -91,7 +91,7 @@ typedef struct lqmpc_options {
                           can counter), the batch is bucket-sorted by its logarithm and the rollout walks it hardest-first, so the
                           instances that share a wavefront leave the constrained regime together; results are written
                           back to their original positions and do not depend on the order.  0: natural order.
-                          -1 auto (1 for specialised rollouts with presolve, T >= 4 and Bsz >= 1024).  (default -1) */
+                          -1 auto (1 for specialised rollouts with presolve, T >= 4 and a batch large enough to pay for the probe: 8192 instances in the 16-lane-row layout, 1024 in the packed one).  (default -1) */
     int32_t warm_start; /* primal-dual active-set warm start: before the interior-point loop, the QP is solved exactly on
                           the face guessed from the unconstrained minimiser (rows outside the box sit on their bound)
                           and the guess is corrected from the KKT signs, up to 8 times; a fixed point is the exact

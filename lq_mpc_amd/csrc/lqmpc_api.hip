@@ -56,8 +56,9 @@ struct lqmpc_handle {
     bool own_stream = false;
     lqmpc_options opt;
     DevBuf shared, ws;
-    DevBuf key, perm, hist, rec;     // difficulty ordering of rollout batches
-    DevBuf fail;                     // r16 rollouts: [count | list] of the instances handed to the packed kernel
+    DevBuf key, perm, rec;           // difficulty ordering of rollout batches (its counters live in `fail`)
+    DevBuf fail;                     // [count (2) | counters of the difficulty order | list] of the instances handed to the packed kernel
+    bool fail_cleared = false;       // build_order zeroed count and counters in this call already
     DevBuf st2, it2;                 // lqmpc_sweep_batch_dev without a fused kernel: status / iters of the max-V_N pass
     DevBuf stage[12];                // host-flavour staging (inputs and outputs)
     std::vector<double> shared_host; // last uploaded shared block
@@ -65,6 +66,8 @@ struct lqmpc_handle {
     const char *last_kernel = "none";
     bool use_wg = false;             // set by prepare(): this call runs on the workgroup kernel
 };
+
+constexpr size_t FAIL_HDR = 2 + (size_t)lqmpc::ORDER_BUCKETS;    // ints in front of the hand-back list: its count, the order's counters
 
 static int ensure(lqmpc_handle *h, DevBuf &b, size_t bytes)
 {
@@ -146,7 +149,7 @@ int lqmpc_destroy(lqmpc_handle *h)
     (void)hipStreamSynchronize(h->stream);
     if (h->shared.p) (void)hipFree(h->shared.p);
     if (h->ws.p) (void)hipFree(h->ws.p);
-    for (DevBuf *b : {&h->key, &h->perm, &h->hist, &h->rec, &h->fail, &h->st2, &h->it2}) if (b->p) (void)hipFree(b->p);
+    for (DevBuf *b : {&h->key, &h->perm, &h->rec, &h->fail, &h->st2, &h->it2}) if (b->p) (void)hipFree(b->p);
     for (auto &b : h->stage) if (b.p) (void)hipFree(b.p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -218,6 +221,7 @@ struct Call {
 // workspace, fill the kernel parameter block.
 static int prepare(lqmpc_handle *h, const Call &c, KParams &p)
 {
+    h->fail_cleared = false;
     int rc = check_dims(c.nx, c.nu, c.N, c.Bsz);
     if (rc) return rc;
     if (!c.Q || !c.R || !c.P || !c.lb || !c.ub) return fail(LQMPC_ERR_BAD_ARG, "Q, R, P, lb, ub must not be NULL");
@@ -295,16 +299,17 @@ static int build_order(lqmpc_handle *h, KParams &p)
     if (B > (size_t)INT32_MAX) return fail(LQMPC_ERR_BAD_ARG, "ordering supports up to 2^31-1 instances");
     int rc = ensure(h, h->key, B * sizeof(double));
     if (!rc) rc = ensure(h, h->perm, B * sizeof(int));
-    if (!rc) rc = ensure(h, h->hist, (size_t)lqmpc::ORDER_BUCKETS * sizeof(int));
+    if (!rc) rc = ensure(h, h->fail, ((size_t)p.Bsz + FAIL_HDR) * sizeof(int));
     const size_t rec_doubles = (size_t)(p.nx * p.nx + p.nx * p.nu + p.nx);
     if (!rc) rc = ensure(h, h->rec, B * rec_doubles * sizeof(double));
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(h->hist.p, 0, (size_t)lqmpc::ORDER_BUCKETS * sizeof(int), h->stream));
+    HIP_TRY(hipMemsetAsync(h->fail.p, 0, FAIL_HDR * sizeof(int), h->stream));    // the hand-back count and the order's counters in one fill
+    h->fail_cleared = true;
     KParams q = p;
     q.mode = lqmpc::MODE_PROBE;
     q.perm = nullptr;
     q.key = (double *)h->key.p;
-    q.hist = (int *)h->hist.p;
+    q.hist = (int *)h->fail.p + 2;
     q.stage = (double *)h->rec.p;
     const char *name = nullptr;
     if (!lqmpc::launch_spec(q, h->stream, &name)) return fail(LQMPC_ERR_UNSUPPORTED, "probe launch failed");
@@ -345,13 +350,22 @@ static bool use_r16(const lqmpc_handle *h, const KParams &p, int64_t Bsz, int64_
 }
 
 // 16-lane-row kernel on the whole batch, then the packed kernel over whatever it handed back (device-side list)
+// the hand-back list of this call: count zeroed (by build_order's fill if it ran), list behind the order's counters
+static int prepare_hand_back(lqmpc_handle *h, KParams &p)
+{
+    int rc = ensure(h, h->fail, ((size_t)p.Bsz + FAIL_HDR) * sizeof(int));
+    if (rc) return rc;
+    if (!h->fail_cleared) HIP_TRY(hipMemsetAsync(h->fail.p, 0, 2 * sizeof(int), h->stream));
+    h->fail_cleared = false;
+    p.fail_count = (int *)h->fail.p;
+    p.fail_list = (int *)h->fail.p + FAIL_HDR;
+    return 0;
+}
+
 static int launch_r16_with_hand_back(lqmpc_handle *h, KParams &p)
 {
-    int rc = ensure(h, h->fail, ((size_t)p.Bsz + 2) * sizeof(int));
+    int rc = prepare_hand_back(h, p);
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(h->fail.p, 0, 2 * sizeof(int), h->stream));
-    p.fail_count = (int *)h->fail.p;
-    p.fail_list = (int *)h->fail.p + 2;
     const char *name = nullptr;
     if (!lqmpc::launch_r16(p, h->stream, &name)) return fail(LQMPC_ERR_UNSUPPORTED, "r16 launch failed");
     HIP_TRY(hipGetLastError());
@@ -428,7 +442,9 @@ int lqmpc_rollout_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
     const bool spec = use_spec(h, nx, nu, N);
     const int order = h->opt.order < 0 ? ((spec && p.presolve && T >= 4 && Bsz >= 1024) ? 1 : 0) : (spec ? h->opt.order : 0);
     if (spec && use_r16(h, p, Bsz, INT32_MAX)) {
-        const int r16_order = h->opt.order < 0 ? ((T >= 4 && Bsz >= 1024) ? 1 : 0) : h->opt.order;
+        // (measured at C3: the sorted walk pays for its probe and scatter launches from about 8 192 instances: 0.26 against 0.31 ms
+        // at 16 384, 0.25 against 0.19 ms at 4 096)
+        const int r16_order = h->opt.order < 0 ? ((T >= 4 && Bsz >= 8192) ? 1 : 0) : h->opt.order;
         if (r16_order) {
             rc = build_order(h, p);
             if (rc) return rc;
@@ -445,11 +461,8 @@ int lqmpc_rollout_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
             p.nwide = nw < 0 ? 0 : (nw > Bsz ? Bsz : nw);
         }
         if (p.nwide > 0) {
-            rc = ensure(h, h->fail, ((size_t)Bsz + 2) * sizeof(int));
+            rc = prepare_hand_back(h, p);
             if (rc) return rc;
-            HIP_TRY(hipMemsetAsync(h->fail.p, 0, 2 * sizeof(int), h->stream));
-            p.fail_count = (int *)h->fail.p;
-            p.fail_list = (int *)h->fail.p + 2;
             rc = launch(h, p);
             if (rc) return rc;
             const char *name = h->last_kernel;
@@ -498,7 +511,7 @@ int lqmpc_sweep_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, i
         // one launch: condensing and W once per instance, K open-loop QPs, then the closed loop
         p.A = dA; p.B = dB; p.x0 = dx0; p.JT = dJT; p.MV = dMV; p.status = dstatus; p.iters = diters;
         if (true_per_instance) { p.At = A_true; p.Bt = B_true; }
-        const int order = h->opt.order < 0 ? ((T >= 4 && Bsz >= 1024) ? 1 : 0) : h->opt.order;
+        const int order = h->opt.order < 0 ? ((T >= 4 && Bsz >= 8192) ? 1 : 0) : h->opt.order;
         if (order) {
             rc = build_order(h, p);
             if (rc) return rc;

@@ -40,7 +40,7 @@ struct KParams {
     int r16_maxit;                        // active-set iteration cap of the 16-lane-row layout before it hands an instance back
 };
 
-constexpr int ORDER_BUCKETS = 4096;          // difficulty buckets of the ordering: 128 per binade of the key over [2^-8, 2^24)
+constexpr int ORDER_BUCKETS = 512;           // difficulty buckets of the ordering: 16 per binade of the key over [2^-8, 2^24)
 
 // ---- fp64 reciprocal / reciprocal square root: hardware seed + Newton steps ----
 // v_rcp_f64 / v_rsq_f64 give a seed good to ~2^-26 or better; two Newton steps reach ~1 ulp

@@ -1224,10 +1224,11 @@ __global__ void __launch_bounds__(64) lqmpc_probe_kernel(KParams p)
     }
     const double kk = (key == key) ? key : 1e300;
     // The order only has to group similar instances, hardest first: a bucket sort on the logarithm of the key (exponent and
-    // seven mantissa bits of the fp64: 128 buckets per binade, clamped to [2^-8, 2^24)).  Each wavefront reserves its
+    // four mantissa bits of the fp64: 16 buckets per binade, clamped to [2^-8, 2^24); finer buckets cost more atomics
+    // than they save in the rollout.  Each wavefront reserves its
     // positions inside a bucket with one atomic per distinct bucket it holds; lqmpc_order_scatter_kernel turns
     // (bucket, position) into the slot of the instance.
-    const int raw = (int)((unsigned)__double2hiint(kk) >> 13) - ((1023 - 8) << 7);
+    const int raw = (int)((unsigned)__double2hiint(kk) >> 16) - ((1023 - 8) << 4);
     const int bucket = raw < 0 ? 0 : (raw > ORDER_BUCKETS - 1 ? ORDER_BUCKETS - 1 : raw);
     const int lane = threadIdx.x;
     int my_leader = lane, rank = 0, cnt = 0;           // the lanes of my bucket: first of them, my rank among them, their number
