@@ -266,7 +266,7 @@ def test_data_generation_reproduces_reference_npz(solver, golden_dir):
 
 
 def test_difficulty_ordering_is_transparent(solver, golden_dir):
-    """options.order = 1 (probe + radix sort, hardest first; the first instances of the order on a wavefront each)
+    """options.order = 1 (probe + bucket sort on the logarithm of the key, hardest first)
     must not change any instance's result beyond the rounding of a different summation order."""
     b = synth.make_batch(3, Bsz=4096 + 37)
     try:
@@ -278,7 +278,7 @@ def test_difficulty_ordering_is_transparent(solver, golden_dir):
         r2 = solver.rollout_batch(20, *args(b), b["x0"], b["A_true"], b["B_true"], want_traj=True)
     finally:
         solver.set_options(order=-1, presolve=-1, warm_start=-1)
-    for k in ("J_T", "X", "U"):                                # same algorithm and iterates; the wide tier sums in another order
+    for k in ("J_T", "X", "U"):                                # same algorithm and iterates; the packed tier and its wide tier sum in different orders
         assert np.abs(r0[k] - r1[k]).max() <= 1e-12 * max(1.0, np.abs(r0[k]).max())
     packed = np.abs(r0["J_T"] - r1["J_T"]) == 0.0
     assert packed.mean() > 0.9                                # everything outside the wide tier is bit-identical
