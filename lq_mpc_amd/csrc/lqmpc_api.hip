@@ -67,7 +67,7 @@ struct lqmpc_handle {
     bool use_wg = false;             // set by prepare(): this call runs on the workgroup kernel
 };
 
-constexpr size_t FAIL_HDR = 2 + (size_t)lqmpc::ORDER_BUCKETS;    // ints in front of the hand-back list: its count, the order's counters
+constexpr size_t FAIL_HDR = 16 + (size_t)lqmpc::ORDER_CELLS * lqmpc::ORDER_PAD;    // ints in front of the hand-back list: its count, the order's counters
 
 static int ensure(lqmpc_handle *h, DevBuf &b, size_t bytes)
 {
@@ -309,7 +309,7 @@ static int build_order(lqmpc_handle *h, KParams &p)
     q.mode = lqmpc::MODE_PROBE;
     q.perm = nullptr;
     q.key = (double *)h->key.p;
-    q.hist = (int *)h->fail.p + 2;
+    q.hist = (int *)h->fail.p + 16;
     q.stage = (double *)h->rec.p;
     const char *name = nullptr;
     if (!lqmpc::launch_spec(q, h->stream, &name)) return fail(LQMPC_ERR_UNSUPPORTED, "probe launch failed");

@@ -31,7 +31,7 @@ struct KParams {
     int *status, *iters;                  // may be null
     const int *perm;                      // processing order (slot -> instance), null = natural order
     double *key;                          // MODE_PROBE output per instance: (difficulty bucket, position inside the bucket), two ints
-    int *hist;                            // MODE_PROBE: instances per difficulty bucket (ORDER_BUCKETS counters, zeroed by the host)
+    int *hist;                            // MODE_PROBE: instances per difficulty bucket (ORDER_CELLS counters, zeroed by the host)
     double *stage;                        // MODE_PROBE output: instance-major [A|B|x0] records (null: none)
     const double *rec;                    // input records staged by the probe (null: read A, B, x0 directly)
     long long nwide;                      // tiered rollout: the first nwide slots of the order get a wavefront each
@@ -40,7 +40,10 @@ struct KParams {
     int r16_maxit;                        // active-set iteration cap of the 16-lane-row layout before it hands an instance back
 };
 
-constexpr int ORDER_BUCKETS = 512;           // difficulty buckets of the ordering: 16 per binade of the key over [2^-8, 2^24)
+constexpr int ORDER_BUCKETS = 512;           // difficulty buckets of the ordering: 16 per binade of the key over [2^-2, 2^30)
+constexpr int ORDER_COPIES = 8;              // counters per bucket (wavefront w uses copy w % 8): spreads the atomics on a popular bucket
+constexpr int ORDER_CELLS = ORDER_BUCKETS * ORDER_COPIES;
+constexpr int ORDER_PAD = 16;                // ints between two counters: one 64-byte line each (atomics on one line serialise)
 
 // ---- fp64 reciprocal / reciprocal square root: hardware seed + Newton steps ----
 // v_rcp_f64 / v_rsq_f64 give a seed good to ~2^-26 or better; two Newton steps reach ~1 ulp

@@ -1224,11 +1224,11 @@ __global__ void __launch_bounds__(64) lqmpc_probe_kernel(KParams p)
     }
     const double kk = (key == key) ? key : 1e300;
     // The order only has to group similar instances, hardest first: a bucket sort on the logarithm of the key (exponent and
-    // four mantissa bits of the fp64: 16 buckets per binade, clamped to [2^-8, 2^24); finer buckets cost more atomics
+    // four mantissa bits of the fp64: 16 buckets per binade, clamped to [2^-2, 2^30): an instance whose key is below 1/4 never meets its bounds; finer buckets cost more atomics
     // than they save in the rollout.  Each wavefront reserves its
     // positions inside a bucket with one atomic per distinct bucket it holds; lqmpc_order_scatter_kernel turns
     // (bucket, position) into the slot of the instance.
-    const int raw = (int)((unsigned)__double2hiint(kk) >> 16) - ((1023 - 8) << 4);
+    const int raw = (int)((unsigned)__double2hiint(kk) >> 16) - ((1023 - 2) << 4);
     const int bucket = raw < 0 ? 0 : (raw > ORDER_BUCKETS - 1 ? ORDER_BUCKETS - 1 : raw);
     const int lane = threadIdx.x;
     int my_leader = lane, rank = 0, cnt = 0;           // the lanes of my bucket: first of them, my rank among them, their number
@@ -1244,23 +1244,24 @@ __global__ void __launch_bounds__(64) lqmpc_probe_kernel(KParams p)
         }
         todo &= ~same;
     }
+    const int cell = bucket * ORDER_COPIES + (int)(blockIdx.x % ORDER_COPIES);
     int base = 0;
-    if (lane == my_leader) base = atomicAdd(&p.hist[bucket], cnt);     // all the wave's reservations in flight at once
+    if (lane == my_leader) base = atomicAdd(&p.hist[cell * ORDER_PAD], cnt);   // all the wave's reservations in flight at once
     base = __shfl(base, my_leader);
-    ((int2 *)p.key)[b] = make_int2(bucket, base + rank);
+    ((int2 *)p.key)[b] = make_int2(cell, base + rank);
 }
 
 // slot of an instance = instances in harder buckets + its position inside its bucket.  Every block scans the bucket counts
 // itself (4096 counters: cheaper than another launch) and places 1024 instances.
 __global__ void __launch_bounds__(256) lqmpc_order_scatter_kernel(const int2 *where, const int *hist, int *perm, long long Bsz)
 {
-    __shared__ int base[ORDER_BUCKETS];
+    __shared__ int base[ORDER_CELLS];
     __shared__ int part[256];
-    constexpr int PER = ORDER_BUCKETS / 256;
+    constexpr int PER = ORDER_CELLS / 256;
     const int t = threadIdx.x;
     int above_in_chunk[PER], sum = 0;
 #pragma unroll
-    for (int e = PER - 1; e >= 0; --e) { above_in_chunk[e] = sum; sum += hist[PER * t + e]; }
+    for (int e = PER - 1; e >= 0; --e) { above_in_chunk[e] = sum; sum += hist[(PER * t + e) * ORDER_PAD]; }
     part[t] = sum;
     __syncthreads();
     for (int d = 1; d < 256; d *= 2) {                       // inclusive suffix sums over the threads' chunks
