@@ -281,24 +281,27 @@ struct Wg {
             }
         }
         const ldsd *sh = shd();
-        // [M_m | A^(m+1)] = A [M_(m-1) | A^m]: one thread per entry of the nx x (nu + nx) matrix (two for the
-        // widest shapes: nx (nu + nx) <= 16 * 24)
+        // The powers of A by doubling, A^(L+i) = A^L A^i for i = 1..L (log2 N dependent levels instead of N: every level is
+        // a barrier and a latency-bound dot product with one wavefront per SIMD), then all M_m = A^m B at once.
         {
-            const int wdt = nu + nx, cnt = nx * wdt;
             auto ma_row = [&](int m, int u) { const int i = (N - 1 - m) * nu + u; return Ma + (i / BS) * BLK + (i % BS) * LD; };
-            auto entry = [&](int e, int m) {
-                const int x = e / wdt, c = e - x * wdt;
-                if (m == 0) {
-                    if (c < nu) ma_row(0, c)[x] = Bm[x * nu + c];
-                    else Xf[x * nx + (c - nu)] = Am[x * nx + (c - nu)];
-                } else if (c < nu) ma_row(m, c)[x] = ldot(Am + x * nx, 1, ma_row(m - 1, c), 1, nx);
-                else Xf[m * nx * nx + x * nx + (c - nu)] = ldot(Am + x * nx, 1, Xf + (m - 1) * nx * nx + (c - nu), nx, nx);   // Xf[m] = A^(m+1)
-            };
-            for (int m = 0; m < N; ++m) {
-                if (t < cnt) entry(t, m);
-                if (t + THREADS < cnt) entry(t + THREADS, m);
+            const int nn = nx * nx, nb_ = nx * nu;
+            for (int e = t; e < nn; e += THREADS) Xf[e] = Am[e];                      // Xf[m] = A^(m+1)
+            for (int e = t; e < nb_; e += THREADS) { const int x = e / nu, c = e - x * nu; ma_row(0, c)[x] = Bm[e]; }
+            __syncthreads();
+            for (int L = 1; L < N; L *= 2) {
+                const int cntp = (L < N - L ? L : N - L) * nn;
+                for (int e = t; e < cntp; e += THREADS) {
+                    const int i = e / nn, r = e - i * nn, x = r / nx, y = r - x * nx;
+                    Xf[(L + i) * nn + r] = ldot(Xf + (L - 1) * nn + x * nx, 1, Xf + i * nn + y, nx, nx);
+                }
                 __syncthreads();
             }
+            for (int e = t; e < (N - 1) * nb_; e += THREADS) {
+                const int m1 = e / nb_, r = e - m1 * nb_, x = r / nu, c = r - x * nu;
+                ma_row(m1 + 1, c)[x] = ldot(Xf + m1 * nn + x * nx, 1, Bm + c, nu, nx);
+            }
+            __syncthreads();
         }
         PROF(0);
         const int wave = t >> 6;
