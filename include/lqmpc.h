@@ -73,7 +73,7 @@ enum lqmpc_kernel {
     LQMPC_KERNEL_GENERIC = 1,     /* any dims up to the limits; one instance per lane, workspace in HBM */
     LQMPC_KERNEL_SPECIALIZED = 2, /* fail with LQMPC_ERR_UNSUPPORTED if no specialisation exists */
     LQMPC_KERNEL_WORKGROUP = 3    /* one instance per 256-thread workgroup, matrices in LDS (32 < N*nu <= 128, nx <= 16,
-                                     zero references, symmetric box); LQMPC_ERR_UNSUPPORTED otherwise */
+                                     nu <= 8, LDS image within 160 KiB); LQMPC_ERR_UNSUPPORTED otherwise */
 };
 
 typedef struct lqmpc_options {
@@ -97,6 +97,17 @@ typedef struct lqmpc_options {
                           and the guess is corrected from the KKT signs, up to 8 times; a fixed point is the exact
                           optimum, otherwise the interior-point loop runs.  -1 auto (= presolve), 0 off, 1 on.
                           Specialised kernels only.  (default -1) */
+    /* ---- layout / tuning selectors (the tests force every path through these; defaults are the measured best) ---- */
+    int32_t layout;     /* which specialised family serves a shape that has both: -1 auto (lqmpc_api.hip: use_r16), 0 the
+                          packed register-resident kernel (and its two-tier launch for sorted rollouts), 1 the 16-lane-row
+                          kernel.  (default -1) */
+    int32_t r16_maxit;  /* active-set iterations the 16-lane-row kernel spends on one QP before it hands the instance back to
+                          the packed kernel's interior-point path (second launch over a device-side list); 0 hands every
+                          constrained QP back.  In [0, 64].  (default 12) */
+    int32_t r16_build;  /* build of the 16-lane-row kernel: -1 auto (the one-wave latency build up to 4 096 instances, the
+                          two-waves throughput build above), 0 throughput build, 1 latency build.  (default -1) */
+    int32_t nwide;      /* packed family, sorted rollouts: how many of the hardest instances get the 16-lane-row layout in
+                          the two-tier launch; -1 auto (min(Bsz/8, 4096)), 0 none.  (default -1) */
 } lqmpc_options;
 
 /* Limits of this build. */

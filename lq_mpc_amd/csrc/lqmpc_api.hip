@@ -108,6 +108,10 @@ void lqmpc_default_options(lqmpc_options *opt)
     opt->presolve = -1;
     opt->order = -1;
     opt->warm_start = -1;
+    opt->layout = -1;
+    opt->r16_maxit = 12;
+    opt->r16_build = -1;
+    opt->nwide = -1;
 }
 
 int lqmpc_create_on_stream(int device, void *hip_stream, lqmpc_handle **out)
@@ -176,6 +180,10 @@ int lqmpc_set_options(lqmpc_handle *h, const lqmpc_options *opt)
     if (opt->presolve < -1 || opt->presolve > 1) return fail(LQMPC_ERR_BAD_ARG, "presolve must be -1, 0 or 1");
     if (opt->order < -1 || opt->order > 1) return fail(LQMPC_ERR_BAD_ARG, "order must be -1, 0 or 1");
     if (opt->warm_start < -1 || opt->warm_start > 1) return fail(LQMPC_ERR_BAD_ARG, "warm_start must be -1, 0 or 1");
+    if (opt->layout < -1 || opt->layout > 1) return fail(LQMPC_ERR_BAD_ARG, "layout must be -1, 0 or 1");
+    if (opt->r16_maxit < 0 || opt->r16_maxit > 64) return fail(LQMPC_ERR_BAD_ARG, "r16_maxit must be in [0,64]");
+    if (opt->r16_build < -1 || opt->r16_build > 1) return fail(LQMPC_ERR_BAD_ARG, "r16_build must be -1, 0 or 1");
+    if (opt->nwide < -1) return fail(LQMPC_ERR_BAD_ARG, "nwide must be -1 (auto) or a count");
     h->opt = *opt;
     return 0;
 }
@@ -266,17 +274,14 @@ static int prepare(lqmpc_handle *h, const Call &c, KParams &p)
     p.eps = h->opt.eps; p.tau = h->opt.tau; p.z0_scale = h->opt.z0_scale;
     p.Bsz = c.Bsz;
     p.sh = (const double *)h->shared.p;
-    {
-        const char *env = getenv("LQMPC_R16_MAXIT");           // test knob: a small cap exercises the hand-back path
-        p.r16_maxit = env ? atoi(env) : 12;
-        if (p.r16_maxit < 0) p.r16_maxit = 0;
-    }
+    p.r16_maxit = h->opt.r16_maxit;                            // a small cap exercises the hand-back path (tests)
+    p.r16_build = h->opt.r16_build;
     if (h->opt.kernel == LQMPC_KERNEL_SPECIALIZED && !lqmpc::spec_available(nx, nu, N))
         return fail(LQMPC_ERR_UNSUPPORTED, "no register-resident specialisation built for these dims");
     h->use_wg = !use_spec(h, nx, nu, N) && (h->opt.kernel == LQMPC_KERNEL_AUTO || h->opt.kernel == LQMPC_KERNEL_WORKGROUP) &&
                 lqmpc::wg_supported(p, c.lb, c.ub);
     if (h->opt.kernel == LQMPC_KERNEL_WORKGROUP && !h->use_wg)
-        return fail(LQMPC_ERR_UNSUPPORTED, "the workgroup kernel needs 32 < N*nu <= 128, nx <= 16, zero references, lb = -ub");
+        return fail(LQMPC_ERR_UNSUPPORTED, "the workgroup kernel needs 32 < N*nu <= 128, nx <= 16 and an LDS image within 160 KiB");
     if (!use_spec(h, nx, nu, N) && !h->use_wg) {
         p.ws_stride = (c.Bsz + 63) / 64 * 64;
         const size_t bytes = (size_t)lqmpc::generic_ws_entries(nx, nu, N) * (size_t)p.ws_stride * sizeof(double);
@@ -339,14 +344,14 @@ static int launch(lqmpc_handle *h, const KParams &p)
 // P and W packed in LDS) for every batch size -- 0.77 ms against 0.97 ms for the two-tier launch of the packed kernel at
 // C3's 65 536 instances, and it also fills the GPU where the packed kernel (16 or 32 instances per wavefront) cannot.
 // One-shot entry points and the fused sweep (built for one wave per SIMD): up to `limit` instances.
-// LQMPC_R16=0/1 forces the choice (development switch; 0 gives the packed kernel and its two-tier launch).
+// options.layout = 0/1 forces the choice (0 gives the packed kernel and its two-tier launch).
 static bool use_r16(const lqmpc_handle *h, const KParams &p, int64_t Bsz, int64_t limit)
 {
-    const char *env = getenv("LQMPC_R16");
+    const int force = h->opt.layout;
     const bool ok = h->opt.kernel == LQMPC_KERNEL_AUTO && p.presolve && p.warm_start && lqmpc::r16_available(p.nx, p.nu, p.N) &&
                     Bsz <= INT32_MAX;
-    if (ok && lqmpc::r16_lanes(p.nx, p.nu, p.N) == 64) return env ? env[0] == '1' : true;   // vs one wave per instance in the packed family too: always
-    return ok && (env ? env[0] == '1' : Bsz <= limit);
+    if (ok && lqmpc::r16_lanes(p.nx, p.nu, p.N) == 64) return force != 0;   // vs one wave per instance in the packed family too: always
+    return ok && (force >= 0 ? force == 1 : Bsz <= limit);
 }
 
 // 16-lane-row kernel on the whole batch, then the packed kernel over whatever it handed back (device-side list)
@@ -362,6 +367,17 @@ static int prepare_hand_back(lqmpc_handle *h, KParams &p)
     return 0;
 }
 
+// status / iters of the instances on a device-side list: worse status, summed iterations (grid-stride over the list)
+__global__ void lqmpc_merge_listed_kernel(int *st, int *it, const int *st2, const int *it2, const int *list, const int *count)
+{
+    const int n = *count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int b = list[i];
+        if (st) st[b] = st[b] > st2[b] ? st[b] : st2[b];
+        if (it) it[b] += it2[b];
+    }
+}
+
 static int launch_r16_with_hand_back(lqmpc_handle *h, KParams &p)
 {
     int rc = prepare_hand_back(h, p);
@@ -373,12 +389,25 @@ static int launch_r16_with_hand_back(lqmpc_handle *h, KParams &p)
     f.perm = p.fail_list; f.count_dev = p.fail_count; f.fail_list = nullptr; f.fail_count = nullptr; f.nwide = 0;
     const char *name2 = nullptr;
     if (p.mode == lqmpc::MODE_SWEEP) {         // the packed kernel has no fused mode: max V_N, then the rollout, over the list
+        // the two passes write status / iters of the listed instances: the max-V_N pass into side buffers, merged below
+        // (status = the worse of the two parts, iters = their sum -- the contract of lqmpc_sweep_batch, as on the two-launch path)
+        if (p.status) { rc = ensure(h, h->st2, (size_t)p.Bsz * sizeof(int32_t)); if (rc) return rc; }
+        if (p.iters) { rc = ensure(h, h->it2, (size_t)p.Bsz * sizeof(int32_t)); if (rc) return rc; }
         f.mode = lqmpc::MODE_MAXVN;
+        f.status = p.status ? (int *)h->st2.p : nullptr;
+        f.iters = p.iters ? (int *)h->it2.p : nullptr;
         if (!lqmpc::launch_spec(f, h->stream, &name2)) return fail(LQMPC_ERR_UNSUPPORTED, "hand-back launch failed");
         f.mode = lqmpc::MODE_ROLLOUT;
+        f.status = p.status; f.iters = p.iters;
     }
     if (!lqmpc::launch_spec(f, h->stream, &name2)) return fail(LQMPC_ERR_UNSUPPORTED, "hand-back launch failed");
     HIP_TRY(hipGetLastError());
+    if (p.mode == lqmpc::MODE_SWEEP && (p.status || p.iters)) {
+        const unsigned blocks = (unsigned)(p.Bsz < 65536 ? (p.Bsz + 255) / 256 : 256);
+        hipLaunchKernelGGL(lqmpc_merge_listed_kernel, dim3(blocks), dim3(256), 0, h->stream, p.status, p.iters,
+                           (const int *)h->st2.p, (const int *)h->it2.p, (const int *)p.fail_list, (const int *)p.fail_count);
+        HIP_TRY(hipGetLastError());
+    }
     h->last_kernel = name;
     return 0;
 }
@@ -456,8 +485,7 @@ int lqmpc_rollout_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
         if (rc) return rc;
         // the hardest instances (first in the order) in the 16-lane-row layout: see lqmpc_spec_tiered_kernel
         if (lqmpc::spec_tiered_available(nx, nu, N) && p.presolve && p.warm_start && Bsz <= INT32_MAX) {
-            const char *env = getenv("LQMPC_NWIDE");          // tuning knob for experiments
-            long long nw = env ? atoll(env) : (Bsz / 8 < 4096 ? Bsz / 8 : 4096) / 4 * 4;   // measured: ~one 16-lane-row wave per SIMD
+            long long nw = h->opt.nwide >= 0 ? h->opt.nwide : (Bsz / 8 < 4096 ? Bsz / 8 : 4096) / 4 * 4;   // measured: ~one 16-lane-row wave per SIMD
             p.nwide = nw < 0 ? 0 : (nw > Bsz ? Bsz : nw);
         }
         if (p.nwide > 0) {

@@ -38,6 +38,7 @@ struct KParams {
     int *fail_list, *fail_count;          // lqmpc_r16_kernel: instances it hands back (status 3), and their number
     const int *count_dev;                 // packed kernel as the fallback pass: number of slots to process, on the device
     int r16_maxit;                        // active-set iteration cap of the 16-lane-row layout before it hands an instance back
+    int r16_build;                        // options.r16_build: -1 auto, 0 throughput build, 1 latency build
 };
 
 constexpr int ORDER_BUCKETS = 512;           // difficulty buckets of the ordering: 16 per binade of the key over [2^-2, 2^30)

@@ -16,8 +16,8 @@
 // row_newbcast: the pivot row reaches the 16 lanes of an instance without leaving the vector registers).  W itself
 // comes from P by the same elimination.
 //
-// Used for whole batches up to 16 384 instances (rollouts; 8 192 for the one-shot entry points) and as the wide
-// tier of larger sorted rollouts (lqmpc_spec_tiered_kernel); the host picks (lqmpc_api.hip: use_r16).
+// Used for whole batches of every size (all entry points; the host picks, lqmpc_api.hip: use_r16) and as the wide
+// tier of the packed family's sorted rollouts (lqmpc_spec_tiered_kernel, options.layout = 0).
 // An instance whose active set does not settle within the iteration cap is reported with status 3 internally; the
 // host re-runs exactly those instances on the packed kernel (interior point + active-set finishing) in a second
 // launch over a device-side list.
@@ -98,8 +98,7 @@ bool launch_r16(const KParams &p, hipStream_t stream, const char **name)
     const R16Entry *e = find_r16(p.nx, p.nu, p.N);
     if (!e) return false;
     // a batch of at most one wave per SIMD: the latency build where the shape has one (lqmpc_r16_lat.hip)
-    const char *env = getenv("LQMPC_R16_LAT");
-    const bool lat = e->lpi == 16 && (env ? env[0] == '1' : p.Bsz <= 4096);
+    const bool lat = e->lpi == 16 && (p.r16_build >= 0 ? p.r16_build == 1 : p.Bsz <= 4096);
     if (!(lat && launch_r16_lat(p, stream))) e->launch(p, stream);
     if (name) *name = e->name;
     return true;

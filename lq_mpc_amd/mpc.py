@@ -59,10 +59,15 @@ def _ptr(a):
 
 
 def _ref_or_none(r, rows, N):
-    """All-zero references (every caller in the reference) are passed as NULL."""
+    """References as the reference reads them: columns 0..N-1 of a (rows, >= N) array (utils_class.py:69, 75 index
+    x_ref[:, i], u_ref[:, i] for i < N only, so wider arrays -- e.g. one long reference shared by several horizons -- are
+    accepted and the tail is ignored).  All-zero references (every caller in the reference) are passed as NULL."""
     if r is None:
         return None
-    r = _f64(r, (rows, N))
+    r = np.asarray(r, dtype=np.float64)
+    if r.ndim != 2 or r.shape[0] != rows or r.shape[1] < N:
+        raise ValueError(f"expected a reference of shape ({rows}, >= {N}), got {r.shape}")
+    r = np.ascontiguousarray(r[:, :N])
     return r if np.any(r) else None
 
 
@@ -234,6 +239,20 @@ class BatchSolver:
         _lib.check(self._L.lqmpc_max_vn_batch_dev(self._h, nx, nu, N, Bsz, x0s.shape[1], _ptr(dA), _ptr(dB), _ptr(Q), _ptr(R),
                                                   _ptr(P), _ptr(lb), _ptr(ub), _ptr(x0s), _ptr(x_ref), _ptr(u_ref),
                                                   _ptr(dMV), _ptr(dstatus), _ptr(diters)))
+
+    def sweep_batch_dev(self, nx, nu, N, Bsz, T, dA, dB, Q, R, P, lb, ub, dx0, x0s, A_true, B_true, dJT, dMV,
+                        dstatus=None, diters=None, true_per_instance=False, x_ref=None, u_ref=None):
+        Q, R, P, lb, ub = _f64(Q, (nx, nx)), _f64(R, (nu, nu)), _f64(P, (nx, nx)), _f64(lb, (nu,)), _f64(ub, (nu,))
+        x0s = _f64(x0s)
+        if x0s.ndim != 2 or x0s.shape[0] != nx:
+            raise ValueError("x0s must be (nx, K)")
+        if not true_per_instance:
+            A_true, B_true = _f64(A_true, (nx, nx)), _f64(B_true, (nx, nu))
+        x_ref, u_ref = _ref_or_none(x_ref, nx, N), _ref_or_none(u_ref, nu, N)
+        _lib.check(self._L.lqmpc_sweep_batch_dev(self._h, nx, nu, N, Bsz, T, x0s.shape[1], _ptr(dA), _ptr(dB), _ptr(Q), _ptr(R),
+                                                 _ptr(P), _ptr(lb), _ptr(ub), _ptr(dx0), _ptr(x0s), _ptr(A_true), _ptr(B_true),
+                                                 1 if true_per_instance else 0, _ptr(x_ref), _ptr(u_ref),
+                                                 _ptr(dJT), _ptr(dMV), _ptr(dstatus), _ptr(diters)))
 
 
 _default_solver = None

@@ -29,23 +29,34 @@ def dlqr_gain(A, B, Q, R):
     return np.linalg.solve(R + B.T @ Pinf @ B, B.T @ Pinf @ A)
 
 
-def local_radius(F_u, K, Q):
-    """epsilon_K = 1 / max_i |(F_u K)_i|^2_{Q^-1}   (utils.py:548-564)."""
-    M = np.asarray(F_u) @ np.asarray(K)
-    invQ = np.linalg.inv(Q)
-    return 1.0 / max(float(M[i] @ invQ @ M[i]) for i in range(M.shape[0]))
+local_radius = bounds.local_radius        # epsilon_K = 1 / max_i |(F_u K)_i|^2_{Q^-1}   (utils.py:548-564)
 
 
-def circle_generator(N_points, ratio_ext_radius, my_base, Q):
-    """Points on x'Qx = (ratio*sqrt(base))^2; 2-state systems only, as utils.py:683-704."""
+def circle_generator(N_points, ratio_ext_radius, my_base, Q, seed=0):
+    """N_points initial states on the level set x'Qx = (ratio*sqrt(base))^2   (utils.py:683-704).
+
+    n_x = 2 is the reference's construction, value for value: the point (r, 0) rotated by theta_k = linspace(0, 2(1-1/N)pi, N)
+    and mapped through the inverse of the upper Cholesky factor of Q.  The reference is hard-wired to two states; for n_x > 2
+     the same circle is drawn in floor(n_x/2) planes of a seeded random orthonormal basis, point k in plane
+    k mod floor(n_x/2), so every point still satisfies x'Qx = r^2 and the set is reproducible from `seed`."""
     Q = np.asarray(Q, dtype=np.float64)
-    if Q.shape != (2, 2):
-        raise ValueError("circle_generator is defined for n_x = 2 (utils.py:683-704)")
+    nx = Q.shape[0]
     root_Q = np.linalg.cholesky(Q).T            # scipy cho_factor's default (upper) factor
-    base = np.array([ratio_ext_radius * math.sqrt(my_base), 0.0])
+    r = ratio_ext_radius * math.sqrt(my_base)
     theta = np.linspace(0, 2 * (1 - 1 / N_points) * math.pi, N_points)
-    pts = np.stack([np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]]) @ base for t in theta], axis=1)
-    return np.linalg.inv(root_Q) @ pts
+    if nx == 2:
+        basis = np.eye(2)
+    else:
+        q, rr = np.linalg.qr(np.random.default_rng(seed).standard_normal((nx, nx)))
+        basis = q * np.sign(np.diag(rr))
+    planes = max(nx // 2, 1)
+    pts = np.zeros((nx, N_points))
+    for k, t in enumerate(theta):
+        p = k % planes
+        e1 = basis[:, 2 * p]
+        e2 = basis[:, 2 * p + 1] if nx > 1 else 0.0
+        pts[:, k] = r * (math.cos(t) * e1 + math.sin(t) * e2)
+    return np.linalg.solve(root_Q, pts)
 
 
 class LQ_RDP_Behavior_Multiple:

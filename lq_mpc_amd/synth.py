@@ -55,8 +55,14 @@ def base_system(config_id):
     return A, B
 
 
-def make_batch(config_id, Bsz=None, fixture_dir=None):
-    """Returns a dict with the batch in SoA layout plus the shared cost/box/plant data."""
+HARD_S = (6.0, 24.0)   # "hard" mix: the unconstrained LQR input at step 0 is s*u_max with s ~ U[6, 24] (default mix: U[0.5, 4])
+
+
+def make_batch(config_id, Bsz=None, fixture_dir=None, mix="default"):
+    """Returns a dict with the batch in SoA layout plus the shared cost/box/plant data.
+
+    mix = "hard": same models, initial states 6-24x outside the region where the box is inactive, so that most MPC steps of a
+    T = 30 rollout are constrained QPs (the default mix of SURVEY 8(d) leaves ~85 % of the steps to the presolve)."""
     c = CONFIGS[config_id]
     nx, nu, N = c["nx"], c["nu"], c["N"]
     Bsz = int(Bsz or c["Bsz"])
@@ -86,7 +92,37 @@ def make_batch(config_id, Bsz=None, fixture_dir=None):
     K = _dlqr_gain(A0, B0, Q, R)
     d = rng.standard_normal((nx, Bsz))
     d /= np.linalg.norm(d, axis=0, keepdims=True)
-    s = rng.uniform(0.5, 4.0, Bsz)
+    s = rng.uniform(0.5, 4.0, Bsz) if mix == "default" else rng.uniform(HARD_S[0], HARD_S[1], Bsz)
     ku = np.max(np.abs(K @ d), axis=0)
     out["x0"] = np.ascontiguousarray(d * (s * U_MAX / ku))
+    out["mix"] = mix
     return out
+
+
+def condense_np(A, B, Q, R, P, N):
+    """H = G'QbarG + Rbar and F = G'Qbar Phi of one model in numpy; cost = U'HU + 2(F x0)'U + c."""
+    nx, nu = B.shape
+    pw = [np.eye(nx)]
+    for _ in range(N):
+        pw.append(A @ pw[-1])
+    G = np.zeros((N * nx, N * nu))
+    for r in range(N):
+        for c in range(r + 1):
+            G[r * nx:(r + 1) * nx, c * nu:(c + 1) * nu] = pw[r - c] @ B
+    Phi = np.vstack(pw[1:])
+    Qb = np.kron(np.eye(N), Q)
+    Qb[-nx:, -nx:] = P
+    return G.T @ Qb @ G + np.kron(np.eye(N), R), G.T @ Qb @ Phi
+
+
+def constrained_share(batch, X, idx):
+    """Share of the MPC steps along the trajectories X (nx, T+1, len(idx)) of instances `idx` whose QP has an unconstrained
+    minimiser outside the box, i.e. the steps the presolve cannot finish (zero references)."""
+    lb, ub = np.tile(batch["lb"], batch["N"])[:, None], np.tile(batch["ub"], batch["N"])[:, None]
+    cons = tot = 0
+    for j, i in enumerate(idx):
+        H, F = condense_np(batch["A"][:, :, i], batch["B"][:, :, i], batch["Q"], batch["R"], batch["P"], batch["N"])
+        v = -np.linalg.solve(H, F @ X[:, :-1, j])
+        cons += int(((v < lb) | (v > ub)).any(axis=0).sum())
+        tot += X.shape[1] - 1
+    return cons / max(tot, 1)

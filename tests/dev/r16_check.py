@@ -20,7 +20,7 @@ if len(sys.argv) > 1:
     dA, dB, dx0 = (torch.from_numpy(a).to(dev) for a in (b['A'], b['B'], b['x0']))
     dJ = torch.empty(K, dtype=torch.float64, device=dev); dit = torch.empty(K, dtype=torch.int32, device=dev); dst = torch.empty(K, dtype=torch.int32, device=dev)
     for env in ('1', '0'):
-        os.environ['LQMPC_R16'] = env
+        s.set_options(layout=int(env))
         for order in (1, 0):
             s.set_options(order=order)
             ts = []

@@ -29,7 +29,8 @@ def test_version_and_defaults():
     o = _lib.Options()
     L.lqmpc_default_options(ctypes.byref(o))
     assert o.eps == 1e-12 and o.max_iter == 50 and o.polish == 1 and o.kernel == _lib.KERNEL_AUTO and o.presolve == -1 and o.order == -1 and o.warm_start == -1
-    assert ctypes.sizeof(_lib.Options) == 48
+    assert o.layout == -1 and o.r16_maxit == 12 and o.r16_build == -1 and o.nwide == -1
+    assert ctypes.sizeof(_lib.Options) == 64
 
 
 def test_no_device_is_an_error_not_a_fallback():
@@ -82,5 +83,21 @@ def test_sweep_host_helpers_match_reference_constants():
     assert abs(eps - 0.04503580745099056) < 1e-15
     x0 = sweep.circle_generator(8, 1.5, eps, Q)
     np.testing.assert_allclose(x0[:, 1], [0.15916231240837822, 0.15916231240837819], rtol=1e-14)
+    # n_x > 2: same level set, seeded planes
+    Q4 = np.diag([1.0, 2.0, 3.0, 4.0]) + 0.1
+    x4 = sweep.circle_generator(8, 1.3, 0.2, Q4)
+    np.testing.assert_allclose(np.einsum("ik,ij,jk->k", x4, Q4, x4), 1.3 ** 2 * 0.2, rtol=1e-13)
+    assert np.linalg.matrix_rank(x4) == 4 and np.array_equal(x4, sweep.circle_generator(8, 1.3, 0.2, Q4))
+    assert sweep.circle_generator(5, 1.0, 1.0, np.eye(3)).shape == (3, 5)
+
+
+def test_references_wider_than_the_horizon_are_accepted():
+    """utils_class.py:69, 75 read x_ref[:, i], u_ref[:, i] for i < N only."""
+    from lq_mpc_amd.mpc import _ref_or_none
+    r = np.arange(12.0).reshape(2, 6)
+    np.testing.assert_array_equal(_ref_or_none(r, 2, 4), r[:, :4])
+    assert _ref_or_none(np.zeros((2, 9)), 2, 4) is None and _ref_or_none(None, 2, 4) is None
     with pytest.raises(ValueError):
-        sweep.circle_generator(8, 1.5, eps, np.eye(3))
+        _ref_or_none(r, 2, 7)
+    with pytest.raises(ValueError):
+        _ref_or_none(r, 3, 4)

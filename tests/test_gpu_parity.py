@@ -197,11 +197,52 @@ def test_full_size_properties(solver, cfg, golden_dir):
     sub = dict(b, A=np.ascontiguousarray(b["A"][:, :, idx]), B=np.ascontiguousarray(b["B"][:, :, idx]))
     ref = orc.solve_batch(*args(sub), np.ascontiguousarray(b["x0"][:, idx]))
     assert rel(g1["V_N"][idx], ref["V_N"]) < TIGHT and u_err(g1["u_0"][:, idx], ref["u_0"]) < RTOL
-    if cfg == 5:
-        return                      # n = 120 runs on the generic kernel: a full-size rollout takes tens of seconds
+    # the full-size rollout of every config (C5: the workgroup kernel, ~30 ms per launch), a sample against the oracle
     r1 = solver.rollout_batch(30, *args(b), b["x0"], b["A_true"], b["B_true"])
+    if cfg == 5:
+        assert solver.last_kernel() == "lqmpc_wg_kernel"
+        idx = idx[:96]
+        sub = dict(b, A=np.ascontiguousarray(b["A"][:, :, idx]), B=np.ascontiguousarray(b["B"][:, :, idx]))
     rr = orc.rollout_batch(30, *args(sub), np.ascontiguousarray(b["x0"][:, idx]), b["A_true"], b["B_true"])
     assert np.all(r1["status"] == 0) and rel(r1["J_T"][idx], rr["J_T"]) < TIGHT
+    # odd symmetry of the closed loop: the rollout from -x0 costs the same
+    r2 = solver.rollout_batch(30, *args(b), -b["x0"], b["A_true"], b["B_true"])
+    assert rel(r1["J_T"], r2["J_T"]) < 1e-9
+
+
+@pytest.mark.parametrize("cfg,bsz", [(2, 1024), (3, 2048), (3, 12288), (4, 512), (5, 48)])
+def test_hard_mix_rollout_vs_oracle(solver, cfg, bsz, golden_dir):
+    """The hard initial-state mix of bench.py's `rollout_hard` leg (synth.make_batch(mix="hard"): x0 6-24x outside the region
+    where the box is inactive): most MPC steps are constrained QPs, so this is the active-set machinery, not the presolve.
+    12 288 instances of C3 also take the sorted walk (probe + bucket order)."""
+    b = synth.make_batch(cfg, Bsz=bsz, fixture_dir=golden_dir, mix="hard")
+    T = 30 if cfg < 5 else 8
+    got = solver.rollout_batch(T, *args(b), b["x0"], b["A_true"], b["B_true"], want_traj=True)
+    ref = orc.rollout_batch(T, *args(b), b["x0"], b["A_true"], b["B_true"], want_traj=True)
+    assert np.all(got["status"] == 0)
+    assert rel(got["J_T"], ref["J_T"]) < TIGHT and u_err(got["U"], ref["U"]) < RTOL
+    assert np.max(np.abs(got["X"] - ref["X"])) < 1e-7 * np.max(np.abs(ref["X"]))
+    m = min(bsz, 128)
+    share = synth.constrained_share(b, ref["X"][:, :, :m], np.arange(m))
+    assert share > (0.5 if T == 30 else 0.3), f"hard mix: only {share:.2f} of the steps are constrained"
+    assert got["iters"].sum() > 0.5 * bsz * T * (0.5 if T == 30 else 0.3)          # at least one factorisation per constrained step, roughly
+
+
+def test_sweep_batch_on_c3_shapes_with_level_set_points(solver):
+    """SURVEY 8(f) rank 1 end to end at n_x = 4: circle_generator's level-set points (seeded planes) feed lqmpc_sweep_batch --
+    M_V over the 8 points and the rollout in one launch -- against the oracle's max_vn + rollout."""
+    from lq_mpc_amd import sweep as sw
+    b = synth.make_batch(3, Bsz=3000)
+    base = float(np.median(np.einsum("ib,ij,jb->b", b["x0"], b["Q"], b["x0"])))
+    x0s = sw.circle_generator(8, 1.5, base, b["Q"])
+    assert x0s.shape == (4, 8)
+    np.testing.assert_allclose(np.einsum("ik,ij,jk->k", x0s, b["Q"], x0s), 1.5 ** 2 * base, rtol=1e-12)
+    g = solver.sweep_batch(30, *args(b), b["x0"], x0s, b["A_true"], b["B_true"])
+    assert "r16" in solver.last_kernel() and np.all(g["status"] == 0)
+    mv = orc.max_vn_batch(*args(b), x0s)
+    jt = orc.rollout_batch(30, *args(b), b["x0"], b["A_true"], b["B_true"])["J_T"]
+    assert rel(g["M_V"], mv) < TIGHT and rel(g["J_T"], jt) < TIGHT
+    assert np.mean(g["M_V"] > 1.0001 * x0s[:, 0] @ b["Q"] @ x0s[:, 0]) > 0.99      # V_N includes x0'Qx0 and then some
 
 
 # ---------------- solver options ----------------
@@ -298,7 +339,7 @@ WG_SHAPES = [(8, 4, 30), (6, 3, 15), (16, 2, 17), (3, 2, 64), (5, 1, 33)]     # 
 
 @pytest.mark.parametrize("nx,nu,N", [(4, 2, 10), (2, 1, 10), (2, 1, 5), (2, 1, 7), (2, 1, 20), (2, 1, 30), (3, 2, 6), (1, 1, 1), (5, 3, 4), (4, 2, 20)] + WG_SHAPES)
 @pytest.mark.parametrize("warm", [0, 1])
-def test_random_problems(solver, nx, nu, N, warm, monkeypatch):
+def test_random_problems(solver, nx, nu, N, warm):
     """Unstable / badly scaled models, dense Q/R/P, asymmetric boxes, references, per-instance plants, on the
     specialised shapes (warm start on / off), on shapes only the generic kernel covers, and on the
     one-instance-per-workgroup shapes (32 < n <= 128, including stages that straddle the 16-row blocks)."""
@@ -325,18 +366,17 @@ def test_random_problems(solver, nx, nu, N, warm, monkeypatch):
     ok = np.isfinite(r2["J_T"]) & (np.abs(r2["X"]).max(axis=(0, 1)) < 1e6)     # diverging plants amplify round-off
     assert ok.mean() > 0.5
     # the two builds of the 16-lane-row kernel (one wave per SIMD for small batches, two for large): both, where both exist
-    builds = ("1", "0") if warm and (nx, nu, N) in [(4, 2, 10), (2, 1, 20)] else (None,)
+    builds = (1, 0) if warm and (nx, nu, N) in [(4, 2, 10), (2, 1, 20)] else (-1,)
     for build in builds:
-        if build is not None: monkeypatch.setenv("LQMPC_R16_LAT", build)
         try:
-            solver.set_options(warm_start=warm, presolve=warm)
+            solver.set_options(warm_start=warm, presolve=warm, r16_build=build)
             g1 = solver.solve_batch(N, A, B, Q, R, P, lb, ub, x0, xr, ur)
             g2 = solver.rollout_batch(T, N, A, B, Q, R, P, lb, ub, x0, At, Bt, xr, ur, want_traj=True)
             k = solver.last_kernel()                                  # packed or 16-lane-row specialisation (small batches, warm start on)
             assert ("spec" in k or "r16" in k or "r64" in k) == ((nx, nu, N) in [(4, 2, 10), (2, 1, 10), (2, 1, 5), (2, 1, 7), (2, 1, 20), (2, 1, 30), (4, 2, 20)])
             assert ("wg" in solver.last_kernel()) == wg
         finally:
-            solver.set_options(warm_start=-1, presolve=-1)
+            solver.set_options(warm_start=-1, presolve=-1, r16_build=-1)
         assert np.all(g1["status"] == 0)
         assert rel(g1["V_N"], r1["V_N"]) < 1e-7 and u_err(g1["u_0"], r1["u_0"], umax) < RTOL
         assert np.all(g2["status"][ok] == 0)
@@ -388,9 +428,9 @@ def test_workgroup_kernel_dispatch_and_agreement(solver):
         solver.set_options(kernel=KERNEL_AUTO)
 
 
-def test_16_lane_row_layout_whole_batch_tiered_and_hand_back(solver, monkeypatch):
+def test_16_lane_row_layout_whole_batch_tiered_and_hand_back(solver):
     """Rollouts of the shapes it serves run entirely in the 16-lane-row layout (lqmpc_r16_body.h; both of its builds,
-    LQMPC_R16_LAT=1/0); the packed family's tiered kernel uses it for its hardest instances (LQMPC_R16=0 + LQMPC_NWIDE).  References, an off-centre box and
+    options.r16_build = 1/0); the packed family's tiered kernel uses it for its hardest instances (options.layout = 0 + nwide).  References, an off-centre box and
     per-instance plants go through it; with its iteration cap forced to 1 it hands the constrained instances back
     (status 3 internally) and the packed kernel's second pass must restore every one."""
     rng = np.random.default_rng(7)
@@ -404,21 +444,19 @@ def test_16_lane_row_layout_whole_batch_tiered_and_hand_back(solver, monkeypatch
     ref = orc.rollout_batch(T, *a, b["x0"], At, Bt, xr, ur, want_traj=True)
     try:
         solver.set_options(order=1)
-        for layout, cap, nwide, lat, name in ((None, None, None, "1", "r16"), (None, "1", None, "1", "r16"), (None, None, None, "0", "r16"),
-                                              (None, "1", None, "0", "r16"), ("0", None, "1024", None, "tiered"),
-                                              ("0", "1", "1024", None, "tiered"), ("0", None, "2048", None, "tiered")):
-            for key, val in (("LQMPC_R16", layout), ("LQMPC_R16_MAXIT", cap), ("LQMPC_NWIDE", nwide), ("LQMPC_R16_LAT", lat)):
-                if val is None: monkeypatch.delenv(key, raising=False)
-                else: monkeypatch.setenv(key, val)
+        for layout, cap, nwide, lat, name in ((-1, 12, -1, 1, "r16"), (-1, 1, -1, 1, "r16"), (-1, 12, -1, 0, "r16"),
+                                              (-1, 1, -1, 0, "r16"), (0, 12, 1024, -1, "tiered"),
+                                              (0, 1, 1024, -1, "tiered"), (0, 12, 2048, -1, "tiered")):
+            solver.set_options(layout=layout, r16_maxit=cap, nwide=nwide, r16_build=lat)
             g = solver.rollout_batch(T, *a, b["x0"], At, Bt, xr, ur, want_traj=True)
             assert name in solver.last_kernel()
             assert np.all(g["status"] == 0)
             assert rel(g["J_T"], ref["J_T"]) < TIGHT and u_err(g["U"], ref["U"]) < RTOL and np.abs(g["X"] - ref["X"]).max() < 1e-7
     finally:
-        solver.set_options(order=-1)
+        solver.set_options(order=-1, layout=-1, r16_maxit=12, nwide=-1, r16_build=-1)
 
 
-def test_sweep_batch_is_max_vn_plus_rollout(solver, monkeypatch):
+def test_sweep_batch_is_max_vn_plus_rollout(solver):
     """lqmpc_sweep_batch = lqmpc_max_vn_batch + lqmpc_rollout_batch for the same models: fused in one launch on the
     16-lane-row layout (C3 and the reference's shapes), two launches elsewhere (C4 shape here), also after a forced hand-back."""
     for cfg, Bsz, fused in ((3, 1500, True), (2, 1000, True), (4, 96, False), (5, 24, False)):
@@ -427,18 +465,36 @@ def test_sweep_batch_is_max_vn_plus_rollout(solver, monkeypatch):
         x0s = np.ascontiguousarray(1.5 * b["x0"][:, :6])
         mv = orc.max_vn_batch(*a, x0s)
         jt = orc.rollout_batch(12, *a, b["x0"], b["A_true"], b["B_true"])["J_T"]
-        for cap, lat in (((None, "1"), ("1", "1"), (None, "0"), ("1", "0")) if fused else ((None, None),)):
-            for key, val in (("LQMPC_R16_MAXIT", cap), ("LQMPC_R16_LAT", lat)):
-                if val is None: monkeypatch.delenv(key, raising=False)
-                else: monkeypatch.setenv(key, val)
+        for cap, lat in (((12, 1), (1, 1), (12, 0), (1, 0)) if fused else ((12, -1),)):
+            solver.set_options(r16_maxit=cap, r16_build=lat)
             g = solver.sweep_batch(12, *a, b["x0"], x0s, b["A_true"], b["B_true"])
             assert ("r16" in solver.last_kernel()) == fused
             assert np.all(g["status"] == 0)
             assert rel(g["M_V"], mv) < TIGHT and rel(g["J_T"], jt) < TIGHT
-            if cap is None and lat != "0": g0 = g
-        monkeypatch.delenv("LQMPC_R16_MAXIT", raising=False)
-        monkeypatch.delenv("LQMPC_R16_LAT", raising=False)
+            if cap == 12 and lat != 0: g0 = g
+        solver.set_options(r16_maxit=12, r16_build=-1)
         m2 = solver.max_vn_batch(*a, x0s)
         r2 = solver.rollout_batch(12, *a, b["x0"], b["A_true"], b["B_true"])
         assert rel(g0["M_V"], m2["M_V"]) < 1e-12 and rel(g0["J_T"], r2["J_T"]) < 1e-12
         assert np.array_equal(g0["iters"], m2["iters"] + r2["iters"])        # iters = the sum of the two parts
+
+
+def test_sweep_hand_back_merges_status_and_iters(solver):
+    """Fused sweep with every constrained QP handed back (r16_maxit = 0) and a one-iteration interior-point budget on the packed
+    kernel's second pass: status must be the worse of the max-V_N and rollout parts and iters their sum, exactly as
+    lqmpc_max_vn_batch + lqmpc_rollout_batch report them (a failed max-V_N must not be overwritten by the rollout's status)."""
+    b = synth.make_batch(3, Bsz=1500)
+    a = (b["N"], b["A"], b["B"], b["Q"], b["R"], b["P"], b["lb"], b["ub"])
+    x0s = np.ascontiguousarray(6.0 * b["x0"][:, :6])                       # far outside: the open-loop QPs are constrained
+    x0 = np.ascontiguousarray(0.05 * b["x0"])                              # the rollouts mostly are not
+    try:
+        solver.set_options(r16_maxit=0, max_iter=1, polish=0)
+        g = solver.sweep_batch(8, *a, x0, x0s, b["A_true"], b["B_true"])
+        assert "r16" in solver.last_kernel()
+        m = solver.max_vn_batch(*a, x0s)
+        r = solver.rollout_batch(8, *a, x0, b["A_true"], b["B_true"])
+        assert np.any(m["status"] == 1) and np.any(r["status"] == 0)       # the case the merge exists for
+        assert np.array_equal(g["status"], np.maximum(m["status"], r["status"]))
+        assert np.array_equal(g["iters"], m["iters"] + r["iters"])
+    finally:
+        solver.set_options(r16_maxit=12, max_iter=50, polish=1)

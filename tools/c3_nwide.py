@@ -1,4 +1,4 @@
-"""Dev experiment: C3-shaped rollout time vs number of wide-tier instances (LQMPC_NWIDE).  usage: c3_nwide.py Bsz nw1 nw2 ..."""
+"""Dev experiment: C3-shaped rollout time vs number of wide-tier instances (options.nwide).  usage: c3_nwide.py Bsz nw1 nw2 ..."""
 import os, sys, time, numpy as np
 import torch
 torch.zeros(1, device='cuda:0')
@@ -11,9 +11,9 @@ dA, dB, dx0 = (torch.from_numpy(a).to(dev) for a in (b['A'], b['B'], b['x0']))
 dJ = torch.empty(K, dtype=torch.float64, device=dev); dit = torch.empty(K, dtype=torch.int32, device=dev); dst = torch.empty(K, dtype=torch.int32, device=dev)
 s = BatchSolver(0)
 ref = None
-os.environ['LQMPC_R16'] = '0'
+s.set_options(layout=0)
 for nw in nws:
-    os.environ['LQMPC_NWIDE'] = str(nw)
+    s.set_options(nwide=nw)
     ts = []
     for rep in range(8):
         torch.cuda.synchronize(); t0 = time.perf_counter()

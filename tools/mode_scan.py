@@ -1,4 +1,4 @@
-"""Dev tool: device-resident one-shot / max-V_N / sweep times over batch sizes, packed vs 16-lane-row (LQMPC_R16=0/1)."""
+"""Dev tool: device-resident one-shot / max-V_N / sweep times over batch sizes, packed vs 16-lane-row (options.layout = 0/1)."""
 import os, sys, time, ctypes, numpy as np, torch
 sys.path.insert(0, '.')
 from lq_mpc_amd import BatchSolver, synth, _lib
@@ -25,7 +25,7 @@ for Bsz in sizes:
            ('maxvn', lambda: s.max_vn_batch_dev(nx, nu, N, Bsz, dA, dB, *c, x0s, dV, dstatus=dst, diters=dit), lambda: dV.sum().item()),
            ('sweep', sweep, lambda: dV.sum().item() + dJ.sum().item()))
     for env in ('0', '1'):
-        os.environ['LQMPC_R16'] = env
+        s.set_options(layout=int(env))
         out = []
         for name, fn, chk in fns:
             best = 1e9
@@ -34,4 +34,4 @@ for Bsz in sizes:
                 for _ in range(5): fn()
                 torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t) / 5)
             out.append('%s %.3f ms [%s bad %d sum %.9g]' % (name, best * 1e3, s.last_kernel().split('<')[0].replace('lqmpc_', ''), int((dst != 0).sum()), chk()))
-        print('C%d Bsz %6d R16=%s: ' % (cfg, Bsz, env) + '  '.join(out), flush=True)
+        print('C%d Bsz %6d layout=%s: ' % (cfg, Bsz, env) + '  '.join(out), flush=True)

@@ -5,7 +5,7 @@ TAG=$1; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-oneshot $@"
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-extras $@"
 for P in "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pmc_$P -- python3 bench.py $ARGS > $OUT/pmc_$P.log 2>&1 || echo "pmc pass failed: $P"
 done
