@@ -54,7 +54,8 @@ def parse_args(argv=None):
                     help="initial-state mix of the headline leg (hard: most steps constrained, lq_mpc_amd/synth.py)")
     ap.add_argument("--kernel", choices=["auto", "generic", "specialized", "workgroup"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the cpu_baseline leg (default: every core this process may use)")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="host threads of the cpu_baseline leg (default 16 = one GPU's share of the box's cores; 0 = every core this process may use)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (one-shot, hard mix, sweep, latency)")
     ap.add_argument("--gather", choices=["final", "per-step"], default="final",
                     help="--gpus > 1: gather J_T once after the timed rollouts (default, north_star) or after every rollout")

@@ -8,6 +8,9 @@
  *                           (one call per instance there; Bsz instances per call here)
  *   lqmpc_rollout_batch  <- LQ_MPC_Simulator.simulate        /root/reference/utils_class.py:245-285
  *   lqmpc_sweep_batch    <- one (error level | horizon) of data_generation: both of the following in one call
+ *   lqmpc_bounds_batch   <- the rest of one pass of data_generation: control.dlqr + LQ_RDP_Calculator.energy_decreasing +
+ *                           energy_bound + the bound               /root/reference/utils_class.py:837-859, 920-942
+ *                                                                  (utils_class.py:308-373; utils.py:78-117, 186-584)
  *   lqmpc_max_vn_batch   <- the M_V loops of
  *                           LQ_RDP_Behavior_Multiple.data_generation
  *                                                            /root/reference/utils_class.py:813-824, 896-907
@@ -80,7 +83,8 @@ typedef struct lqmpc_options {
     double eps;        /* relative tolerance on complementarity gap and dual residual (default 1e-12) */
     double tau;        /* fraction-to-the-boundary of the interior-point step (default 0.999) */
     double z0_scale;   /* initial multipliers = z0_scale * |q|_inf (default 0.1) */
-    int32_t max_iter;  /* interior-point iteration cap per QP (default 50) */
+    int32_t max_iter;  /* interior-point iteration cap per QP; also caps the <= 8 active-set warm-start iterations of the packed
+                          kernel (default 50) */
     int32_t polish;    /* 1: finish with an exact solve on the identified active set (default 1) */
     int32_t kernel;    /* enum lqmpc_kernel (default AUTO) */
     int32_t presolve;  /* unconstrained-minimiser shortcut: the minimiser v = G x + v_r (G = -P^-1 Fq, built once
@@ -207,6 +211,32 @@ int lqmpc_sweep_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, i
                           const double *A_true, const double *B_true, int true_per_instance,
                           const double *x_ref, const double *u_ref,
                           double *dJT, double *dMV, int32_t *dstatus, int32_t *diters);
+
+/* ---- the coefficients of the reference's performance bound, per system (utils_class.py:837-859, 920-942) ----
+ * For every model (A, B) of the batch: K = control.dlqr(A, B, Q, R) (utils_class.py:840); with the gain -K, the error levels
+ * e_A[b], e_B[b] and the energy bar M_V[b] (lqmpc_max_vn_batch's output; NULL = 0): xi, eta of
+ * LQ_RDP_Calculator.energy_decreasing (utils_class.py:344-373) and eps = local_radius (utils.py:548-564); with the state x
+ * (n_x, shared) and the parameter triple p (3, positive): alpha, beta of energy_bound (utils_class.py:308-342); and
+ * bound = (alpha V_expert + beta) / (1 - xi - eta) (utils_class.py:858-859).  The box (lb, ub) stands for the rows of F_u
+ * (e_k / ub_k, e_k / lb_k; bounds must be non-zero); bar_u and bar_d_u (two Gurobi QPs in utils.py:592-650) are closed forms for a box.
+ * Outputs are per instance, any may be NULL: K[(k*nx + a)*Bsz + b] (dlqr's sign: u = -K x), alpha, beta, xi, eta, bound, eps [b],
+ * aux[j*Bsz + b] for j < 8 = gamma, rho(A - BK), |A|_2, |B|_2, |Gamma|_2, |Phi|_2, lambda_min(hat H), |K|_2 (diagnostics),
+ * status[b] = 0 ok, 1 the Riccati doubling did not settle in 64 steps, 2 non-finite / not stabilisable.
+ * Q, R (symmetric positive definite), lb, ub, x, p are HOST pointers in both flavours. */
+int lqmpc_bounds_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
+                       const double *A, const double *B, const double *Q, const double *R,
+                       const double *lb, const double *ub,
+                       const double *e_A, const double *e_B, const double *MV,
+                       const double *x, const double *p, double V_expert,
+                       double *K, double *alpha, double *beta, double *xi, double *eta, double *bound, double *eps,
+                       double *aux, int32_t *status);
+int lqmpc_bounds_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
+                           const double *dA, const double *dB, const double *Q, const double *R,
+                           const double *lb, const double *ub,
+                           const double *de_A, const double *de_B, const double *dMV,
+                           const double *x, const double *p, double V_expert,
+                           double *dK, double *dalpha, double *dbeta, double *dxi, double *deta, double *dbound, double *deps,
+                           double *daux, int32_t *dstatus);
 
 /* ---- timing on the handle's stream (hipEvents), for bench.py's roofline ----
  * begin/end bracket any number of *_dev calls; end waits for the stream and returns the

@@ -25,6 +25,7 @@ EXPORTS = [
     "lqmpc_rollout_batch", "lqmpc_rollout_batch_dev",
     "lqmpc_max_vn_batch", "lqmpc_max_vn_batch_dev",
     "lqmpc_sweep_batch", "lqmpc_sweep_batch_dev",
+    "lqmpc_bounds_batch", "lqmpc_bounds_batch_dev",
     "lqmpc_timer_begin", "lqmpc_timer_end",
 ]
 
@@ -92,6 +93,9 @@ def lib():
     sweep_args = dims + [ctypes.c_int, ctypes.c_int] + [P] * 11 + [ctypes.c_int] + [P] * 6
     L.lqmpc_sweep_batch.argtypes = sweep_args
     L.lqmpc_sweep_batch_dev.argtypes = sweep_args
+    bounds_args = dims + [P] * 11 + [ctypes.c_double] + [P] * 9
+    L.lqmpc_bounds_batch.argtypes = bounds_args
+    L.lqmpc_bounds_batch_dev.argtypes = bounds_args
     L.lqmpc_timer_begin.argtypes = [_H]
     L.lqmpc_timer_end.argtypes = [_H, ctypes.POINTER(ctypes.c_float)]
     _lib = L

@@ -1,9 +1,11 @@
 // lqmpc_api.hip -- host side of the C ABI declared in include/lqmpc.h: handle, argument checks,
 // shared-block packing, workspace management, kernel dispatch, host<->device staging.
 #include "lqmpc_common.h"
+#include "lqmpc_bounds.h"
 #include "../../include/lqmpc.h"
 
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -212,6 +214,60 @@ static int check_dims(int nx, int nu, int N, int64_t Bsz)
         return fail(LQMPC_ERR_BAD_ARG, buf);
     }
     return 0;
+}
+
+// small host-side dense helpers for the batch-shared weights (lqmpc_bounds_batch): SPD inverse, extreme eigenvalues
+static bool host_spd_inverse(std::vector<double> &M, int n)
+{
+    for (int k = 0; k < n; ++k) {
+        const double d = M[k * n + k];
+        if (!(d > 0.0) || !std::isfinite(d)) return false;
+        const double p = 1.0 / d;
+        M[k * n + k] = 1.0;
+        for (int j = 0; j < n; ++j) M[k * n + j] *= p;
+        for (int i = 0; i < n; ++i) {
+            if (i == k) continue;
+            const double f = M[i * n + k];
+            M[i * n + k] = 0.0;
+            for (int j = 0; j < n; ++j) M[i * n + j] -= f * M[k * n + j];
+        }
+    }
+    return true;
+}
+
+static bool host_sym_eig_extremes(const double *Min, int n, double &emax, double &emin)
+{
+    std::vector<double> M(Min, Min + n * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j)
+            if (std::fabs(M[i * n + j] - M[j * n + i]) > 1e-12 * (std::fabs(M[i * n + i]) + std::fabs(M[j * n + j]))) return false;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int p = 0; p < n; ++p) {
+            dg += M[p * n + p] * M[p * n + p];
+            for (int q = p + 1; q < n; ++q) off += M[p * n + q] * M[p * n + q];
+        }
+        if (!(off > 1e-32 * (dg + off))) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = M[p * n + q];
+                if (std::fabs(apq) < 1e-300) continue;
+                const double theta = (M[q * n + q] - M[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = M[k * n + p], akq = M[k * n + q];
+                    M[k * n + p] = c * akp - s * akq; M[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = M[p * n + k], aqk = M[q * n + k];
+                    M[p * n + k] = c * apk - s * aqk; M[q * n + k] = s * apk + c * aqk;
+                }
+            }
+    }
+    emax = -1e308; emin = 1e308;
+    for (int p = 0; p < n; ++p) { emax = std::max(emax, M[p * n + p]); emin = std::min(emin, M[p * n + p]); }
+    return std::isfinite(emax) && std::isfinite(emin);
 }
 
 static bool use_spec(const lqmpc_handle *h, int nx, int nu, int N)
@@ -698,6 +754,97 @@ int lqmpc_sweep_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int T
                                dJT, dMV, dst, dit);
     if (rc) return rc;
     s.back(JT, dJT, b); s.back(MV, dMV, b); s.back(status, dst, b); s.back(iters, dit, b);
+    if (s.rc) return s.rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- the bound coefficients of data_generation: lqmpc_bounds.hip ----
+int lqmpc_bounds_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, const double *dA, const double *dB,
+                           const double *Q, const double *R, const double *lb, const double *ub, const double *de_A,
+                           const double *de_B, const double *dMV, const double *x, const double *p3, double V_expert,
+                           double *dK, double *dalpha, double *dbeta, double *dxi, double *deta, double *dbound, double *deps,
+                           double *daux, int32_t *dstatus)
+{
+    if (!h || !dA || !dB || !Q || !R || !lb || !ub || !de_A || !de_B || !x || !p3) return fail(LQMPC_ERR_BAD_ARG, "NULL argument");
+    int rc = check_dims(nx, nu, N, Bsz);
+    if (rc) return rc;
+    for (int k = 0; k < nu; ++k)
+        if (!(ub[k] > lb[k]) || !std::isfinite(lb[k]) || !std::isfinite(ub[k]) || lb[k] == 0.0 || ub[k] == 0.0)
+            return fail(LQMPC_ERR_BAD_ARG, "every input needs a finite box with lb < ub and non-zero bounds (rows of F_u)");
+    for (int k = 0; k < 3; ++k)
+        if (!(p3[k] > 0.0)) return fail(LQMPC_ERR_BAD_ARG, "p must be positive");
+    HIP_TRY(hipSetDevice(h->device));
+    // batch-shared block: Q | R | Q^-1 | R^-1 | lb | ub | x | p | (qmax qmin rmax rmin V_expert bar_u bar_d_u)
+    std::vector<double> sh;
+    auto put = [&](const double *src, int count) { int off = (int)sh.size(); sh.insert(sh.end(), src, src + count); return off; };
+    lqmpc::BoundsParams bp;
+    memset(&bp, 0, sizeof bp);
+    bp.oQ = put(Q, nx * nx); bp.oR = put(R, nu * nu);
+    std::vector<double> Qi(Q, Q + nx * nx), Ri(R, R + nu * nu);
+    double qmax, qmin, rmax, rmin;
+    if (!host_sym_eig_extremes(Q, nx, qmax, qmin) || !host_sym_eig_extremes(R, nu, rmax, rmin) || !(qmin > 0.0) || !(rmin > 0.0) ||
+        !host_spd_inverse(Qi, nx) || !host_spd_inverse(Ri, nu))
+        return fail(LQMPC_ERR_BAD_ARG, "Q and R must be symmetric positive definite");
+    bp.oQinv = put(Qi.data(), nx * nx); bp.oRinv = put(Ri.data(), nu * nu);
+    bp.olb = put(lb, nu); bp.oub = put(ub, nu); bp.ox = put(x, nx); bp.op = put(p3, 3);
+    double bar_u = 0.0, bar_du = 0.0;                    // max |u|^2 and max |u1 - u2|^2 over the box (utils.py:592-650 solves two QPs for these)
+    for (int k = 0; k < nu; ++k) { bar_u += std::max(lb[k] * lb[k], ub[k] * ub[k]); bar_du += (ub[k] - lb[k]) * (ub[k] - lb[k]); }
+    const double sc[7] = {qmax, qmin, rmax, rmin, V_expert, bar_u, bar_du};
+    bp.osc = put(sc, 7);
+    rc = ensure(h, h->shared, std::max(sh.size(), (size_t)8192) * sizeof(double));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->shared.p, sh.data(), sh.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->shared_host.clear();                              // the solver's cached copy of the shared block is gone
+    bp.nx = nx; bp.nu = nu; bp.N = N; bp.Bsz = Bsz;
+    bp.A = dA; bp.B = dB; bp.eA = de_A; bp.eB = de_B; bp.MV = dMV; bp.sh = (const double *)h->shared.p;
+    bp.o = lqmpc::bounds_offsets(nx, nu, N);
+    bp.K = dK; bp.alpha = dalpha; bp.beta = dbeta; bp.xi = dxi; bp.eta = deta; bp.bound = dbound; bp.eps = deps; bp.aux = daux;
+    bp.status = dstatus;
+    // workspace: at most ~1 GiB at a time, the batch in chunks of whole wavefronts
+    const size_t per = (size_t)bp.o.total * sizeof(double);
+    long long chunk = (long long)(((size_t)1 << 30) / per) / 64 * 64;
+    if (chunk < 64) chunk = 64;
+    if (chunk > (Bsz + 63) / 64 * 64) chunk = (Bsz + 63) / 64 * 64;
+    rc = ensure(h, h->ws, per * (size_t)chunk);
+    if (rc) return rc;
+    bp.ws = (double *)h->ws.p; bp.stride = chunk;
+    for (long long b0 = 0; b0 < Bsz; b0 += chunk) {
+        bp.b0 = b0; bp.b1 = std::min<long long>(Bsz, b0 + chunk);
+        lqmpc::launch_bounds(bp, h->stream);
+        HIP_TRY(hipGetLastError());
+    }
+    h->last_kernel = "lqmpc_bounds_kernel";
+    return 0;
+}
+
+int lqmpc_bounds_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, const double *A, const double *B,
+                       const double *Q, const double *R, const double *lb, const double *ub, const double *e_A,
+                       const double *e_B, const double *MV, const double *x, const double *p3, double V_expert,
+                       double *K, double *alpha, double *beta, double *xi, double *eta, double *bound, double *eps,
+                       double *aux, int32_t *status)
+{
+    if (!h || !A || !B || !e_A || !e_B) return fail(LQMPC_ERR_BAD_ARG, "NULL argument");
+    int rc = check_dims(nx, nu, N, Bsz);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    // (the workspace of the kernel is h->ws; staging uses its own buffers.  Twelve staging slots are in use at most.)
+    Stager s{h};
+    const size_t b = (size_t)Bsz;
+    const double *dA = s.in(A, b * nx * nx), *dB = s.in(B, b * nx * nu), *deA = s.in(e_A, b), *deB = s.in(e_B, b), *dMV = s.in(MV, b);
+    double *dK = s.out(K, b * nu * nx), *dal = s.out(alpha, b), *dbe = s.out(beta, b), *dxi = s.out(xi, b), *det = s.out(eta, b);
+    double *dbd = s.out(bound, b), *dep = s.out(eps, b);
+    if (s.rc) return s.rc;
+    // aux (8 doubles per instance) and status share no staging slot with the above: reuse the ordering buffers of the solver
+    double *dax = nullptr; int32_t *dst = nullptr;
+    if (aux) { rc = ensure(h, h->rec, b * 8 * sizeof(double)); if (rc) return rc; dax = (double *)h->rec.p; }
+    if (status) { rc = ensure(h, h->st2, b * sizeof(int32_t)); if (rc) return rc; dst = (int32_t *)h->st2.p; }
+    rc = lqmpc_bounds_batch_dev(h, nx, nu, N, Bsz, dA, dB, Q, R, lb, ub, deA, deB, dMV, x, p3, V_expert, dK, dal, dbe, dxi, det, dbd, dep,
+                                dax, dst);
+    if (rc) return rc;
+    s.back(K, dK, b * nu * nx); s.back(alpha, dal, b); s.back(beta, dbe, b); s.back(xi, dxi, b); s.back(eta, det, b);
+    s.back(bound, dbd, b); s.back(eps, dep, b); s.back(aux, dax, b * 8); s.back(status, dst, b);
     if (s.rc) return s.rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;

@@ -67,6 +67,9 @@ static void launch_r16_one(const KParams &p, hipStream_t stream)
         (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_r16_prof), sizeof z);
         fprintf(stderr, "r16 prof (block %d ticks): chains %lld images+T %lld suffix/P %lld Fq %lld qr %lld invert %lld G/store %lld | rollout %lld\n",
                 PROFBLK, z[0], z[1], z[2], z[3], z[4], z[5], z[6], z[7]);
+        fprintf(stderr, "r16 prof (grid): waves %lld  set-up %.0f  total %.0f ticks/wave | free wave-steps %lld at %.0f ticks | busy wave-steps %lld at %.0f ticks, "
+                "%.2f wave-iterations each (steps 1..T-1)\n", z[15], (double)z[13] / z[15], (double)z[14] / z[15], z[10], (double)z[8] / (z[10] ? z[10] : 1),
+                z[11], (double)z[9] / (z[11] ? z[11] : 1), (double)z[12] / (z[11] ? z[11] : 1));
 #endif
     }
 }

@@ -20,12 +20,16 @@ using wg::dpp_settle;
 __device__ long long g_r16_prof[16];
 #define RPROF(k) do { const long long now_ = clock64(); if (threadIdx.x == 0 && blockIdx.x == PROFBLK) g_r16_prof[k] += now_ - prof_t; prof_t = clock64(); } while (0)
 #define RPROF_START long long prof_t = clock64()
+// whole-grid accounting (every wavefront adds): [8] cycles of iteration-free wave-steps, [9] cycles of wave-steps with active-set
+// iterations, [10] / [11] their numbers, [12] wave-iterations, [13] set-up cycles, [14] total cycles, [15] wavefronts
+#define RPROF_ADD(k, v) do { if (threadIdx.x == 0) atomicAdd((unsigned long long *)&g_r16_prof[k], (unsigned long long)(v)); } while (0)
 #ifndef PROFBLK
 #define PROFBLK 0
 #endif
 #else
 #define RPROF(k) do { } while (0)
 #define RPROF_START do { } while (0)
+#define RPROF_ADD(k, v) do { } while (0)
 #endif
 
 typedef unsigned long long mask_t;        // one bit per row of an instance (n <= 64)
@@ -213,6 +217,10 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     // a loop.  The row images ma, P_T ma, Q ma and the powers of A sit in LDS (the W region and the vectors
     // behind it, free until the inverse is stored).
     double G[RB][NX], vr[RB];
+#ifdef LQMPC_R16_PROF
+    const long long prof_t0 = clock64();
+    int prof_wit = 0;
+#endif
     {
         RPROF_START;
         ldsd *MA = Wp, *PM = MA + n * NX, *QM = PM + n * NX, *AP = QM + n * NX;
@@ -478,6 +486,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         RPROF(6);
     }
     RPROF_START;
+    RPROF_ADD(13, clock64() - prof_t0);
 
     // ---------------- the requested operation ----------------
     // an opaque copy of the instance index for everything below: the addresses derived from it are recomputed here instead of
@@ -670,6 +679,9 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                     nf = nf || (vrow[s] && !(fabs(v[s]) < 1e300));
                 }
                 const bool rownf = iballot<LPI>(nf, q) != 0;
+#ifdef LQMPC_R16_PROF
+                prof_wit += 1;
+#endif
                 if (busy) {
                     iters += 1;
                     if (rowfail || rownf) { failed = true; busy = false; }
@@ -847,8 +859,19 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
             for (int a = 0; a < NX; ++a) p.X[((long long)a * (p.T + 1)) * Bsz + bq] = x[a];
         }
+#ifdef LQMPC_R16_PROF
+        long long prof_ts = 0, prof_acc[5] = {0, 0, 0, 0, 0};
+#endif
         for (int t = 0; t < p.T; ++t) {
             double v[RB], u[NU], xn[NX];
+#ifdef LQMPC_R16_PROF
+            if (t > 0) {
+                const long long d_ = clock64() - prof_ts;
+                if (prof_wit) { prof_acc[1] += d_; prof_acc[3] += 1; prof_acc[4] += prof_wit; } else { prof_acc[0] += d_; prof_acc[2] += 1; }
+            }
+            prof_ts = clock64();
+            prof_wit = 0;
+#endif
             qp(x, v);
             const double um = fmin(fmax(v[0], -h[0]), h[0]) + ctr[0];     // the input of my first row: u_i in lane i < NU
             stage_input(v, 0, u);
@@ -884,6 +907,10 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
         for (int k = 0; k < NU; ++k) cost += ibcast<LPI>(costu, k);
         RPROF(7);
+#ifdef LQMPC_R16_PROF
+        for (int k_ = 0; k_ < 5; ++k_) RPROF_ADD(8 + k_, prof_acc[k_]);
+#endif
+        RPROF_ADD(14, clock64() - prof_t0); RPROF_ADD(15, 1);
         if (writer) p.JT[b] = cost;
     }
     if (writer) {

@@ -675,7 +675,7 @@ struct Spec {
                 for (int jb = 0; jb < RB; ++jb) own |= rowbit(jb);
                 myL = gl & own; myU = gu & own;
             }
-            if (pdas(p, myL, myU, todo, 8, gtol, iters)) todo = false;
+            if (pdas(p, myL, myU, todo, p.max_iter < 8 ? p.max_iter : 8, gtol, iters)) todo = false;   // (max_iter caps the warm start too)
         }
         if (__any(todo)) {
             // Fallback.  With the polish on, the interior-point loop is run in stages (gap 1e-6, 1e-9, eps) and

@@ -211,6 +211,28 @@ class BatchSolver:
                                              _ptr(x_ref), _ptr(u_ref), _ptr(JT), _ptr(MV), _ptr(status), _ptr(iters)))
         return {"J_T": JT, "M_V": MV, "status": status, "iters": iters}
 
+    def bounds_batch(self, N, A, B, Q, R, lb, ub, e_A, e_B, M_V, x, p, V_expert, want_aux=False):
+        """Per model of the batch: dlqr gain K and the coefficients alpha, beta, xi, eta, bound of the reference's performance
+        bound (utils_class.py:837-859: control.dlqr + energy_decreasing + energy_bound), on the GPU (lqmpc_bounds_batch).
+        e_A, e_B, M_V: (Bsz,) arrays (scalars are broadcast; M_V may be None = 0)."""
+        A, B, nx, nu, Bsz = self._dims(A, B)
+        Q, R, lb, ub = _f64(Q, (nx, nx)), _f64(R, (nu, nu)), _f64(lb, (nu,)), _f64(ub, (nu,))
+        e_A = np.ascontiguousarray(np.broadcast_to(np.asarray(e_A, dtype=np.float64), (Bsz,)))
+        e_B = np.ascontiguousarray(np.broadcast_to(np.asarray(e_B, dtype=np.float64), (Bsz,)))
+        M_V = None if M_V is None else np.ascontiguousarray(np.broadcast_to(np.asarray(M_V, dtype=np.float64), (Bsz,)))
+        x, p = _f64(x, (nx,)), _f64(p, (3,))
+        out = {k: np.empty(Bsz) for k in ("alpha", "beta", "xi", "eta", "bound", "eps")}
+        out["K"] = np.empty((nu, nx, Bsz))
+        out["status"] = np.empty(Bsz, dtype=np.int32)
+        aux = np.empty((8, Bsz)) if want_aux else None
+        _lib.check(self._L.lqmpc_bounds_batch(self._h, nx, nu, N, Bsz, _ptr(A), _ptr(B), _ptr(Q), _ptr(R), _ptr(lb), _ptr(ub),
+                                              _ptr(e_A), _ptr(e_B), _ptr(M_V), _ptr(x), _ptr(p), float(V_expert),
+                                              _ptr(out["K"]), _ptr(out["alpha"]), _ptr(out["beta"]), _ptr(out["xi"]),
+                                              _ptr(out["eta"]), _ptr(out["bound"]), _ptr(out["eps"]), _ptr(aux), _ptr(out["status"])))
+        if want_aux:
+            out.update(dict(zip(("gamma", "rho_cl", "norm_A", "norm_B", "norm_Gamma", "norm_Phi", "min_eig_H", "norm_K"), aux)))
+        return out
+
     # ---- device-pointer entry points (torch tensors / raw addresses already in HBM; asynchronous) ----
     def solve_batch_dev(self, nx, nu, N, Bsz, dA, dB, Q, R, P, lb, ub, dx0, du0, dVN, dstatus=None, diters=None,
                         x_ref=None, u_ref=None):
@@ -253,6 +275,15 @@ class BatchSolver:
                                                  _ptr(P), _ptr(lb), _ptr(ub), _ptr(dx0), _ptr(x0s), _ptr(A_true), _ptr(B_true),
                                                  1 if true_per_instance else 0, _ptr(x_ref), _ptr(u_ref),
                                                  _ptr(dJT), _ptr(dMV), _ptr(dstatus), _ptr(diters)))
+
+    def bounds_batch_dev(self, nx, nu, N, Bsz, dA, dB, Q, R, lb, ub, de_A, de_B, dMV, x, p, V_expert, dK=None, dalpha=None,
+                         dbeta=None, dxi=None, deta=None, dbound=None, deps=None, daux=None, dstatus=None):
+        Q, R, lb, ub = _f64(Q, (nx, nx)), _f64(R, (nu, nu)), _f64(lb, (nu,)), _f64(ub, (nu,))
+        x, p = _f64(x, (nx,)), _f64(p, (3,))
+        _lib.check(self._L.lqmpc_bounds_batch_dev(self._h, nx, nu, N, Bsz, _ptr(dA), _ptr(dB), _ptr(Q), _ptr(R), _ptr(lb), _ptr(ub),
+                                                  _ptr(de_A), _ptr(de_B), _ptr(dMV), _ptr(x), _ptr(p), float(V_expert),
+                                                  _ptr(dK), _ptr(dalpha), _ptr(dbeta), _ptr(dxi), _ptr(deta), _ptr(dbound),
+                                                  _ptr(deps), _ptr(daux), _ptr(dstatus)))
 
 
 _default_solver = None

@@ -9,27 +9,17 @@ data_generation that is the MPC hot path:
 The reference issues 57 001 sequential cvxpy solves for this; here every (error level, system) pair
 is one instance of ONE batched launch per horizon, read straight from the reference's .npy files
 (their memory layout already is the library's instance-minor layout, utils_class.py:749-750).
-The scalar bound coefficients alpha / beta / xi / bound (utils_class.py:837-859, 920-942) are O(N) host
-formulas per system (lq_mpc_amd/bounds.py); with them data_generation returns, and optionally saves, the
-same 13 arrays as the reference's data_lq_mpc_multipleSys.npz (utils_class.py:944-958).
+The bound coefficients alpha / beta / xi / bound of every system (control.dlqr + energy_decreasing + energy_bound,
+utils_class.py:837-859, 920-942) come from the GPU as well (lqmpc_bounds_batch, one instance per lane); with them
+data_generation returns, and optionally saves, the same 13 arrays as the reference's data_lq_mpc_multipleSys.npz
+(utils_class.py:944-958).
 """
 import math
 import os
 
 import numpy as np
 
-from . import bounds
 from .mpc import box_from_Fu, default_solver
-
-
-def dlqr_gain(A, B, Q, R):
-    """K of control.dlqr (u = -K x), via scipy's DARE (utils_class.py:761)."""
-    from scipy.linalg import solve_discrete_are
-    Pinf = solve_discrete_are(A, B, Q, R)
-    return np.linalg.solve(R + B.T @ Pinf @ B, B.T @ Pinf @ A)
-
-
-local_radius = bounds.local_radius        # epsilon_K = 1 / max_i |(F_u K)_i|^2_{Q^-1}   (utils.py:548-564)
 
 
 def circle_generator(N_points, ratio_ext_radius, my_base, Q, seed=0):
@@ -81,24 +71,29 @@ class LQ_RDP_Behavior_Multiple:
         self.error_A = np.load(os.path.join(data_dir, f"error_A_{norm_type}.npy"))      # (nx, nx, N_sys, 10)
         self.error_B = np.load(os.path.join(data_dir, f"error_B_{norm_type}.npy"))      # (nx, nu, N_sys, 10)
         self._solver = solver
-        K_lqr = dlqr_gain(self.A_true, self.B_true, self.Q, self.R)
-        self.epsilon_lqr = local_radius(self.F_u, -K_lqr, self.Q)                        # utils_class.py:764
+        self._eps_lqr = None
 
     def _s(self):
         return self._solver if self._solver is not None else default_solver()
 
+    @property
+    def epsilon_lqr(self):
+        """local_radius(F_u, -K_lqr, Q) of the true system (utils_class.py:761-764): dlqr and the radius from the GPU."""
+        if self._eps_lqr is None:
+            nx = self.A_true.shape[0]
+            r = self._s().bounds_batch(1, self.A_true[:, :, None], self.B_true[:, :, None], self.Q, self.R, self.lb, self.ub,
+                                       0.0, 0.0, None, np.zeros(nx), np.ones(3), 0.0)
+            if r["status"][0] != 0:
+                raise RuntimeError("dlqr of the true system did not converge (not stabilisable?)")
+            self._eps_lqr, self.K_lqr = float(r["eps"][0]), r["K"][:, :, 0].copy()
+        return self._eps_lqr
+
     def _bound_tables(self, N, A_stack, B_stack, e_level, M_V, x_start, V_expert, p):
-        """alpha, beta, xi, bound for a list of models sharing horizon N (utils_class.py:837-859)."""
-        m = A_stack.shape[2]
-        al, be, xi, bd = np.zeros(m), np.zeros(m), np.zeros(m), np.zeros(m)
-        for j in range(m):
-            A, B = A_stack[:, :, j], B_stack[:, :, j]
-            K = dlqr_gain(A, B, self.Q, self.R)
-            ed = bounds.energy_decreasing(N, A, B, self.Q, self.R, self.F_u, e_level[j], e_level[j], -K, M_V[j])
-            eb = bounds.energy_bound(N, A, B, self.Q, self.R, self.lb, self.ub, e_level[j], e_level[j], x_start, p)
-            al[j], be[j], xi[j] = eb["alpha"], eb["beta"], ed["xi"]
-            bd[j] = (al[j] * V_expert + be[j]) / (1 - xi[j] - ed["eta"])
-        return al, be, xi, bd
+        """alpha, beta, xi, bound for a batch of models sharing horizon N (utils_class.py:837-859): one launch."""
+        r = self._s().bounds_batch(N, A_stack, B_stack, self.Q, self.R, self.lb, self.ub, e_level, e_level, M_V, x_start, p, V_expert)
+        if np.any(r["status"] != 0):
+            raise RuntimeError(f"lqmpc_bounds_batch: {int(np.sum(r['status'] != 0))} models without a stabilising dlqr gain")
+        return r["alpha"], r["beta"], r["xi"], r["bound"]
 
     def data_generation(self, N_points, ext_radius_max, info_ref, p=None, save_path=None):
         s = self._s()

@@ -1,6 +1,6 @@
-"""Scalar coefficients of the reference's performance bound, host side.
+"""TEST INFRASTRUCTURE (host numpy oracle of lqmpc_bounds_batch; only tests/ may import it).
 
-Restates, vectorised over nothing (they are O(N) scalar formulas per system), what
+Scalar coefficients of the reference's performance bound: restates, one system at a time, what
 LQ_RDP_Calculator.energy_decreasing / energy_bound (/root/reference/utils_class.py:308-373) compute
 through /root/reference/utils.py:
     g functions                    utils.py:78-117      stage(g_x, g_u)
@@ -12,12 +12,13 @@ through /root/reference/utils.py:
     h                              utils.py:526-538
     L_V, N_0                       utils.py:567-584
     bar_u, bar_d_u                 utils.py:592-650     (two Gurobi toy QPs there; closed form for a box here)
-so that lq_mpc_amd.sweep can emit all 13 arrays of data_lq_mpc_multipleSys.npz.  They are pinned by the
-reference's own npz (tests/test_bounds.py).  Two quirks of the reference are kept on purpose because the
+The product computes the same numbers on the GPU (lq_mpc_amd/csrc/lqmpc_bounds.hip); this file is what that kernel is checked
+against, and it is itself pinned by the reference's own npz (tests/test_bounds.py).  Two quirks of the reference are kept on purpose because the
 golden data contain them: the constant lambda_K = 1.21 and the "+0.4" in rho_K (utils.py:358, 364).
 One is NOT kept: the reference forms the closed loop as `A + B * K` (elementwise, utils.py:356), which
 equals A + B @ K only for n_u = 1; this module uses the matrix product (identical on the golden data).
 """
+# parity: pinned (alpha/beta/xi/bound tables of data_lq_mpc_multipleSys.npz, tests/test_bounds.py)
 import math
 
 import numpy as np

@@ -72,15 +72,11 @@ def test_product_path_does_not_import_oracle():
 
 
 def test_sweep_host_helpers_match_reference_constants():
-    """circle_generator / local_radius / dlqr restated for the product's sweep driver (SURVEY 8(c) constants)."""
+    """circle_generator restated for the product's sweep driver (SURVEY 8(c) constants; K and eps come from the GPU there,
+    tests/test_gpu_bounds.py)."""
     from lq_mpc_amd import sweep
-    A0 = np.array([[1.0, 0.7], [0.12, 0.4]]); B0 = np.array([[1.0], [1.2]])
-    Q, R = 2.0 * np.eye(2), np.eye(1)
-    F_u = np.vstack((10 * np.eye(1), -10 * np.eye(1)))
-    K = sweep.dlqr_gain(A0, B0, Q, R)
-    np.testing.assert_allclose(K, [[0.48363093, 0.45846723]], rtol=1e-7)
-    eps = sweep.local_radius(F_u, -K, Q)
-    assert abs(eps - 0.04503580745099056) < 1e-15
+    Q = 2.0 * np.eye(2)
+    eps = 0.04503580745099056
     x0 = sweep.circle_generator(8, 1.5, eps, Q)
     np.testing.assert_allclose(x0[:, 1], [0.15916231240837822, 0.15916231240837819], rtol=1e-14)
     # n_x > 2 (SURVEY 8(f) rank 1): same level set, seeded planes

@@ -1,13 +1,13 @@
-"""CPU: the scalar bound coefficients against the reference's npz.
+"""CPU: the host oracle of the bound coefficients (oracle/bounds_np.py) against the reference's npz.
 
-M_V and V_expert come from the oracle here (CPU); tests/test_gpu_parity.py feeds the same formulas with
-the GPU's M_V through lq_mpc_amd.sweep."""
+M_V and V_expert come from the QP oracle here (CPU); tests/test_gpu_bounds.py checks the HIP kernel (lqmpc_bounds_batch) against
+this oracle and against the same npz."""
 import os
 
 import numpy as np
 import pytest
 
-from lq_mpc_amd import bounds, sweep
+from oracle import bounds_np as bounds
 from oracle import oracle as orc
 
 A0 = np.array([[1.0, 0.7], [0.12, 0.4]])
@@ -28,9 +28,9 @@ def test_tables_against_reference_npz(golden_dir):
     eA = np.load(os.path.join(golden_dir, "error_A_f.npy"))
     eB = np.load(os.path.join(golden_dir, "error_B_f.npy"))
     lb, ub = np.array([-0.1]), np.array([0.1])
-    K = sweep.dlqr_gain(A0, B0, Q, R)
-    eps = sweep.local_radius(F_U, -K, Q)
-    x0_vec = sweep.circle_generator(8, 1.5, eps, Q)
+    K = orc.dlqr_gain(A0, B0, Q, R)[0]
+    eps = orc.local_radius(F_U, -K, Q)
+    x0_vec = orc.circle_generator(8, 1.5, eps, Q)
     xs = x0_vec[:, 1]
     V_expert = orc.solve(30, A0, B0, Q, R, Q, lb, ub, xs)["V_N"]
     A = (A0[:, :, None, None] + eA).reshape(2, 2, 1000)
@@ -41,7 +41,7 @@ def test_tables_against_reference_npz(golden_dir):
     for i in range(10):
         for j in range(0, 100, 7):          # a sample of rows keeps the CPU suite fast
             Am, Bm = A0 + eA[:, :, j, i], B0 + eB[:, :, j, i]
-            Km = sweep.dlqr_gain(Am, Bm, Q, R)
+            Km = orc.dlqr_gain(Am, Bm, Q, R)[0]
             ed = bounds.energy_decreasing(7, Am, Bm, Q, R, F_U, err[i], err[i], -Km, MV[j, i])
             eb = bounds.energy_bound(7, Am, Bm, Q, R, lb, ub, err[i], err[i], xs, P_PAIR)
             xi[j, i], al[j, i], be[j, i] = ed["xi"], eb["alpha"], eb["beta"]

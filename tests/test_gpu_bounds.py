@@ -1,0 +1,116 @@
+"""GPU (-m gpu): lqmpc_bounds_batch -- dlqr + energy_decreasing + energy_bound per system on the device
+-- through the C ABI, against the host oracle (oracle/bounds_np.py, scipy's DARE) and the reference's npz.
+
+Tolerances: the numbers are smooth functions of eigenvalues / singular values computed by different methods on the two sides
+(doubling + Jacobi sweeps + repeated squaring on the GPU; LAPACK on the host): 1e-9 relative, 1e-8 against the npz as in
+tests/test_bounds.py."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bounds_np
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+A0 = np.array([[1.0, 0.7], [0.12, 0.4]])
+B0 = np.array([[1.0], [1.2]])
+Q2 = 2.0 * np.eye(2)
+R1 = np.eye(1)
+F_U = np.vstack((10 * np.eye(1), -10 * np.eye(1)))
+P3 = np.array([0.1, 1, 0.6])
+
+
+def rel(a, b):
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))
+
+
+def host_reference(N, A, B, Q, R, lb, ub, eA, eB, MV, x, p, V):
+    F_u = np.vstack([np.diag(1.0 / ub), np.diag(1.0 / lb)])
+    out = {k: [] for k in ("alpha", "beta", "xi", "eta", "bound", "eps", "K", "gamma", "rho_cl", "norm_Gamma", "norm_Phi", "min_eig_H")}
+    for j in range(A.shape[2]):
+        Aj, Bj = A[:, :, j], B[:, :, j]
+        K = orc.dlqr_gain(Aj, Bj, Q, R)[0]
+        ed = bounds_np.energy_decreasing(N, Aj, Bj, Q, R, F_u, eA[j], eB[j], -K, MV[j])
+        eb = bounds_np.energy_bound(N, Aj, Bj, Q, R, lb, ub, eA[j], eB[j], x, p)
+        st = bounds_np.stability_numbers(Aj, Bj, Q, R, -K)
+        G, Phi = bounds_np.gamma_phi(N, Aj, Bj)
+        hatH = np.kron(R, np.eye(N)) + G.T @ np.kron(Q, np.eye(N + 1)) @ G
+        for k, v in (("alpha", eb["alpha"]), ("beta", eb["beta"]), ("xi", ed["xi"]), ("eta", ed["eta"]),
+                     ("bound", (eb["alpha"] * V + eb["beta"]) / (1 - ed["xi"] - ed["eta"])),
+                     ("eps", bounds_np.local_radius(F_u, -K, Q)), ("K", K), ("gamma", st["gamma"]),
+                     ("rho_cl", np.max(np.abs(np.linalg.eigvals(Aj - Bj @ K)))), ("norm_Gamma", np.linalg.norm(G, 2)),
+                     ("norm_Phi", np.linalg.norm(Phi, 2)), ("min_eig_H", np.min(np.linalg.eigvalsh(0.5 * (hatH + hatH.T))))):
+            out[k].append(v)
+    return {k: np.array(v) for k, v in out.items()}
+
+
+def test_reference_systems_against_host_oracle_and_npz(solver, golden_dir):
+    """The reference's 1 000 perturbed systems at N = 7 (utils_class.py:802-859): every coefficient against the host oracle, and
+    the four tables of the npz (M_V from the GPU's own max-V_N pass, as in data_generation)."""
+    d = np.load(os.path.join(golden_dir, "data_lq_mpc_multipleSys.npz"))
+    eA = np.load(os.path.join(golden_dir, "error_A_f.npy")); eB = np.load(os.path.join(golden_dir, "error_B_f.npy"))
+    A = np.ascontiguousarray((A0[:, :, None, None] + eA).reshape(2, 2, 1000)); B = np.ascontiguousarray((B0[:, :, None, None] + eB).reshape(2, 1, 1000))
+    lb, ub = np.array([-0.1]), np.array([0.1])
+    r0 = solver.bounds_batch(7, A0[:, :, None], B0[:, :, None], Q2, R1, lb, ub, 0.0, 0.0, None, np.zeros(2), np.ones(3), 0.0)
+    assert r0["status"][0] == 0
+    np.testing.assert_allclose(r0["K"][:, :, 0], [[0.48363093, 0.45846723]], rtol=1e-7)
+    assert abs(r0["eps"][0] - 0.04503580745099056) < 1e-14
+    x0_vec = orc.circle_generator(8, 1.5, r0["eps"][0], Q2)
+    xs = x0_vec[:, 1]
+    V = float(d["V_expert"])
+    MV = solver.max_vn_batch(7, A, B, Q2, R1, Q2, lb, ub, x0_vec)["M_V"]
+    lev = np.tile(d["error"], 100)                                      # instance (j, i) has error level error[i]
+    g = solver.bounds_batch(7, A, B, Q2, R1, lb, ub, lev, lev, MV, xs, P3, V, want_aux=True)
+    assert np.all(g["status"] == 0)
+    for k, name in (("xi", "xi_table_error"), ("alpha", "alpha_table_error"), ("beta", "beta_table_error"), ("bound", "bound_table_error")):
+        np.testing.assert_allclose(g[k].reshape(100, 10), d[name], rtol=1e-8, err_msg=name)
+    idx = np.arange(0, 1000, 9)
+    h = host_reference(7, A[:, :, idx], B[:, :, idx], Q2, R1, lb, ub, lev[idx], lev[idx], MV[idx], xs, P3, V)
+    for k in ("alpha", "beta", "xi", "eta", "bound", "eps", "gamma", "rho_cl", "norm_Gamma", "norm_Phi", "min_eig_H"):
+        assert rel(g[k][idx], h[k]) < 1e-9, k
+    assert np.max(np.abs(g["K"][:, :, idx].transpose(2, 0, 1) - h["K"])) < 1e-10
+
+
+@pytest.mark.parametrize("nx,nu,N,Bsz", [(4, 2, 10, 300), (3, 3, 5, 130), (8, 4, 12, 70), (2, 1, 30, 64), (5, 2, 1, 40)])
+def test_random_systems_dense_weights(solver, nx, nu, N, Bsz):
+    """Random stabilisable models, dense SPD Q and R (exercises the Kronecker ordering of hat H, utils.py:316-319), asymmetric box,
+    per-instance error levels and energy bars."""
+    rng = np.random.default_rng(10 * nx + nu + N)
+    A = rng.standard_normal((nx, nx, Bsz))
+    A *= rng.uniform(0.3, 1.2, Bsz) / np.abs(np.linalg.eigvals(A.transpose(2, 0, 1))).max(axis=1)
+    B = rng.standard_normal((nx, nu, Bsz))
+    def spd(m, lo, hi):
+        M = rng.standard_normal((m, m)); M = M @ M.T / m + np.eye(m)
+        return M * rng.uniform(lo, hi)
+    Q, R = spd(nx, 0.5, 3.0), spd(nu, 0.2, 2.0)
+    lb, ub = -rng.uniform(0.05, 0.5, nu), rng.uniform(0.05, 0.5, nu)
+    eA, eB = rng.uniform(1e-3, 1e-2, Bsz), rng.uniform(1e-3, 1e-2, Bsz)
+    MV = rng.uniform(0.1, 5.0, Bsz)
+    x, p, V = rng.standard_normal(nx) * 0.2, np.array([0.3, 1.5, 0.7]), 1.7
+    A, B = np.ascontiguousarray(A), np.ascontiguousarray(B)
+    g = solver.bounds_batch(N, A, B, Q, R, lb, ub, eA, eB, MV, x, p, V, want_aux=True)
+    assert solver.last_kernel() == "lqmpc_bounds_kernel" and np.all(g["status"] == 0)
+    h = host_reference(N, A, B, Q, R, lb, ub, eA, eB, MV, x, p, V)
+    assert np.max(np.abs(g["K"].transpose(2, 0, 1) - h["K"])) < 1e-9 * max(1.0, np.abs(h["K"]).max())
+    for k in ("eps", "rho_cl", "norm_Gamma", "norm_Phi", "min_eig_H", "alpha", "beta"):
+        assert rel(g[k], h[k]) < 1e-9, k
+    # gamma = C / (1 - (rho + 0.4)^2) has a pole at rho = 0.6: compare where it is well conditioned
+    ok = np.abs(1 - (h["rho_cl"] + 0.4) ** 2) > 1e-3
+    assert ok.mean() > 0.9
+    for k in ("gamma", "xi", "eta", "bound"):
+        fin = ok & np.isfinite(h[k])
+        assert rel(g[k][fin], h[k][fin]) < 1e-7, k
+
+
+def test_unstabilisable_model_is_reported(solver):
+    A = np.zeros((2, 2, 70)); A[0, 0] = 1.5; A[1, 1] = 0.5
+    B = np.zeros((2, 1, 70)); B[1, 0] = 1.0                        # the unstable mode is not reachable
+    B[0, 0, 35:] = 1.0                                              # ... except in the second half of the batch
+    g = solver.bounds_batch(5, A, B, Q2, R1, [-0.1], [0.1], 1e-3, 1e-3, 1.0, np.ones(2), np.ones(3), 1.0)
+    assert np.all(g["status"][:35] != 0) and np.all(g["status"][35:] == 0)
+    with pytest.raises(Exception):
+        solver.bounds_batch(5, A, B, Q2, -R1, [-0.1], [0.1], 1e-3, 1e-3, 1.0, np.ones(2), np.ones(3), 1.0)     # R not SPD
+    with pytest.raises(Exception):
+        solver.bounds_batch(5, A, B, Q2, R1, [0.0], [0.1], 1e-3, 1e-3, 1.0, np.ones(2), np.ones(3), 1.0)      # a zero bound is no row of F_u

@@ -224,8 +224,9 @@ def test_hard_mix_rollout_vs_oracle(solver, cfg, bsz, golden_dir):
     assert np.max(np.abs(got["X"] - ref["X"])) < 1e-7 * np.max(np.abs(ref["X"]))
     m = min(bsz, 128)
     share = synth.constrained_share(b, ref["X"][:, :, :m], np.arange(m))
-    assert share > (0.5 if T == 30 else 0.3), f"hard mix: only {share:.2f} of the steps are constrained"
-    assert got["iters"].sum() > 0.5 * bsz * T * (0.5 if T == 30 else 0.3)          # at least one factorisation per constrained step, roughly
+    floor = 0.5 if cfg == 3 else 0.3                 # C3 is the bench leg: most of its steps must be constrained
+    assert share > floor, f"hard mix: only {share:.2f} of the steps are constrained"
+    assert got["iters"].sum() > 0.5 * bsz * T * floor          # at least one factorisation per constrained step, roughly
 
 
 def test_sweep_batch_on_c3_shapes_with_level_set_points(solver):

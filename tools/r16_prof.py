@@ -7,7 +7,7 @@ if os.environ.get('LQMPC_LIB'): _lib.LIB_PATH = os.path.abspath(os.environ['LQMP
 dev = torch.device('cuda', 0)
 s = BatchSolver(0, stream=torch.cuda.current_stream(dev).cuda_stream)
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-b = synth.make_batch(cfg)
+b = synth.make_batch(cfg, mix=sys.argv[2] if len(sys.argv) > 2 else 'default')
 nx, nu, N, Bsz, T = b['A'].shape[0], b['B'].shape[1], b['N'], b['Bsz'], 30
 dA = torch.from_numpy(b['A']).to(dev); dB = torch.from_numpy(b['B']).to(dev); dx0 = torch.from_numpy(b['x0']).to(dev)
 dJ = torch.empty(Bsz, dtype=torch.float64, device=dev)
