@@ -221,7 +221,8 @@ int lqmpc_sweep_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, i
  * (e_k / ub_k, e_k / lb_k; bounds must be non-zero); bar_u and bar_d_u (two Gurobi QPs in utils.py:592-650) are closed forms for a box.
  * Outputs are per instance, any may be NULL: K[(k*nx + a)*Bsz + b] (dlqr's sign: u = -K x), alpha, beta, xi, eta, bound, eps [b],
  * aux[j*Bsz + b] for j < 8 = gamma, rho(A - BK), |A|_2, |B|_2, |Gamma|_2, |Phi|_2, lambda_min(hat H), |K|_2 (diagnostics),
- * status[b] = 0 ok, 1 the Riccati doubling did not settle in 64 steps, 2 non-finite / not stabilisable.
+ * status[b] = 0 ok, 1 the Riccati doubling did not settle in 64 steps, 2 not stabilisable / non-finite data (no gain), 3 the gain
+ * and eps are valid but the bound's formulas leave the reals (gamma < 0 when rho(A - BK) + 0.4 > 1, utils.py:358-371).
  * Q, R (symmetric positive definite), lb, ub, x, p are HOST pointers in both flavours. */
 int lqmpc_bounds_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
                        const double *A, const double *B, const double *Q, const double *R,

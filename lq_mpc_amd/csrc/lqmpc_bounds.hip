@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(64) lqmpc_bounds_kernel(BoundsParams p)
     const double sp = sqrt(E_psi), su = sqrt(E_u), spu = sqrt(E_psi_u);
     const double alpha = fmax(p0 * sp + p2 * spu + p0 * sp * p2 * spu, p1 * su);               // utils_class.py:332-335
     const double beta = (1.0 + p0 * sp) * (spu / p2 + E_psi_u) + su / p1 + E_u + sp / p0 + E_psi;   // utils_class.py:338-340
-    if (!(fabs(alpha) < 1e300) || !(fabs(beta) < 1e300) || !(fabs(xi) < 1e300)) status = status ? status : 2;
+    if (!(fabs(alpha) < 1e300) || !(fabs(beta) < 1e300) || !(fabs(xi) < 1e300) || !(fabs(eta) < 1e300)) status = status ? status : 3;
 
     if (p.alpha) p.alpha[b] = alpha;
     if (p.beta) p.beta[b] = beta;

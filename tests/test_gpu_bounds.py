@@ -32,7 +32,10 @@ def host_reference(N, A, B, Q, R, lb, ub, eA, eB, MV, x, p, V):
     for j in range(A.shape[2]):
         Aj, Bj = A[:, :, j], B[:, :, j]
         K = orc.dlqr_gain(Aj, Bj, Q, R)[0]
-        ed = bounds_np.energy_decreasing(N, Aj, Bj, Q, R, F_u, eA[j], eB[j], -K, MV[j])
+        try:
+            ed = bounds_np.energy_decreasing(N, Aj, Bj, Q, R, F_u, eA[j], eB[j], -K, MV[j])
+        except ValueError:                   # rho(A - BK) + 0.4 > 1 makes gamma negative: math domain error in the reference's formulas too
+            ed = {"xi": np.nan, "eta": np.nan}
         eb = bounds_np.energy_bound(N, Aj, Bj, Q, R, lb, ub, eA[j], eB[j], x, p)
         st = bounds_np.stability_numbers(Aj, Bj, Q, R, -K)
         G, Phi = bounds_np.gamma_phi(N, Aj, Bj)
@@ -79,7 +82,7 @@ def test_random_systems_dense_weights(solver, nx, nu, N, Bsz):
     per-instance error levels and energy bars."""
     rng = np.random.default_rng(10 * nx + nu + N)
     A = rng.standard_normal((nx, nx, Bsz))
-    A *= rng.uniform(0.3, 1.2, Bsz) / np.abs(np.linalg.eigvals(A.transpose(2, 0, 1))).max(axis=1)
+    A *= rng.uniform(0.2, 0.9, Bsz) / np.abs(np.linalg.eigvals(A.transpose(2, 0, 1))).max(axis=1)
     B = rng.standard_normal((nx, nu, Bsz))
     def spd(m, lo, hi):
         M = rng.standard_normal((m, m)); M = M @ M.T / m + np.eye(m)
@@ -91,14 +94,17 @@ def test_random_systems_dense_weights(solver, nx, nu, N, Bsz):
     x, p, V = rng.standard_normal(nx) * 0.2, np.array([0.3, 1.5, 0.7]), 1.7
     A, B = np.ascontiguousarray(A), np.ascontiguousarray(B)
     g = solver.bounds_batch(N, A, B, Q, R, lb, ub, eA, eB, MV, x, p, V, want_aux=True)
-    assert solver.last_kernel() == "lqmpc_bounds_kernel" and np.all(g["status"] == 0)
+    assert solver.last_kernel() == "lqmpc_bounds_kernel"
     h = host_reference(N, A, B, Q, R, lb, ub, eA, eB, MV, x, p, V)
+    # status 3 = non-finite coefficients: exactly the models for which the reference's formulas leave the reals
+    # (gamma < 0 when rho(A - BK) + 0.4 > 1, utils.py:358-371)
+    assert np.array_equal(g["status"] == 0, np.isfinite(h["xi"])) and np.mean(g["status"] == 0) > 0.5 and np.all((g["status"] == 0) | (g["status"] == 3))
     assert np.max(np.abs(g["K"].transpose(2, 0, 1) - h["K"])) < 1e-9 * max(1.0, np.abs(h["K"]).max())
     for k in ("eps", "rho_cl", "norm_Gamma", "norm_Phi", "min_eig_H", "alpha", "beta"):
         assert rel(g[k], h[k]) < 1e-9, k
     # gamma = C / (1 - (rho + 0.4)^2) has a pole at rho = 0.6: compare where it is well conditioned
-    ok = np.abs(1 - (h["rho_cl"] + 0.4) ** 2) > 1e-3
-    assert ok.mean() > 0.9
+    ok = (np.abs(1 - (h["rho_cl"] + 0.4) ** 2) > 1e-3) & (g["status"] == 0)
+    assert ok.mean() > 0.4
     for k in ("gamma", "xi", "eta", "bound"):
         fin = ok & np.isfinite(h[k])
         assert rel(g[k][fin], h[k][fin]) < 1e-7, k
@@ -109,7 +115,9 @@ def test_unstabilisable_model_is_reported(solver):
     B = np.zeros((2, 1, 70)); B[1, 0] = 1.0                        # the unstable mode is not reachable
     B[0, 0, 35:] = 1.0                                              # ... except in the second half of the batch
     g = solver.bounds_batch(5, A, B, Q2, R1, [-0.1], [0.1], 1e-3, 1e-3, 1.0, np.ones(2), np.ones(3), 1.0)
-    assert np.all(g["status"][:35] != 0) and np.all(g["status"][35:] == 0)
+    assert np.all((g["status"][:35] == 1) | (g["status"][:35] == 2)) and np.all((g["status"][35:] == 0) | (g["status"][35:] == 3))
+    K = orc.dlqr_gain(A[:, :, 40], B[:, :, 40], Q2, R1)[0]
+    assert np.max(np.abs(g["K"][:, :, 40] - K)) < 1e-10
     with pytest.raises(Exception):
         solver.bounds_batch(5, A, B, Q2, -R1, [-0.1], [0.1], 1e-3, 1e-3, 1.0, np.ones(2), np.ones(3), 1.0)     # R not SPD
     with pytest.raises(Exception):
