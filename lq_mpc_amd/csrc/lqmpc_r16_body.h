@@ -17,8 +17,8 @@ using wg::fmac_rowb_self4;
 using wg::dpp_settle;
 
 #ifdef LQMPC_R16_PROF
-__device__ long long g_r16_prof[16];
-#define RPROF(k) do { const long long now_ = clock64(); if (threadIdx.x == 0 && blockIdx.x == PROFBLK) g_r16_prof[k] += now_ - prof_t; prof_t = clock64(); } while (0)
+__device__ long long g_r16_prof[32];
+#define RPROF(k) do { const long long now_ = clock64(); if (threadIdx.x == 0 && blockIdx.x == PROFBLK) g_r16_prof[k] += now_ - prof_t; if (k < 7) prof_ph[k] += now_ - prof_t; prof_t = clock64(); } while (0)
 #define RPROF_START long long prof_t = clock64()
 // whole-grid accounting (every wavefront adds): [8] cycles of iteration-free wave-steps, [9] cycles of wave-steps with active-set
 // iterations, [10] / [11] their numbers, [12] wave-iterations, [13] set-up cycles, [14] total cycles, [15] wavefronts
@@ -113,6 +113,33 @@ template <int LPI>
 __device__ __forceinline__ void isettle(double &x)
 {
     if constexpr (LPI == 16) dpp_settle(x);
+}
+// 32-bit value of lane c of my 16-lane row (compiler builtin: it places the wait states itself)
+__device__ __forceinline__ int rowb_i(int x, int c)
+{
+    switch (c) {
+#define LQMPC_X(C) case C: return __builtin_amdgcn_update_dpp(0, x, 0x150 + C, 0xF, 0xF, true);
+        LQMPC_ROWB_CASES(LQMPC_X)
+#undef LQMPC_X
+    }
+    return x;
+}
+// reductions over the 16 lanes of a row by rotations (row_ror 8, 4, 2, 1): every lane ends up with the result
+__device__ __forceinline__ unsigned row_or(unsigned x)
+{
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xF, 0xF, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xF, 0xF, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xF, 0xF, false);
+    return x;
+}
+__device__ __forceinline__ unsigned row_umax(unsigned x)
+{
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, false));
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xF, 0xF, false));
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xF, 0xF, false));
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xF, 0xF, false));
+    return x;
 }
 
 // One wavefront's work: the four instances in slots slot0 .. slot0 + 3 (slots >= slot_end are surplus).
@@ -219,7 +246,9 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     double G[RB][NX], vr[RB];
 #ifdef LQMPC_R16_PROF
     const long long prof_t0 = clock64();
-    int prof_wit = 0;
+    int prof_wit = 0, prof_slow = 0, prof_fast = 0;
+    long long prof_slowt = 0;
+    long long prof_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     {
         RPROF_START;
@@ -568,15 +597,140 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         if (__ballot(busy) != 0ull) {
 #pragma unroll 1
             for (int it = 0; it < p.r16_maxit; ++it) {
+#ifdef LQMPC_R16_PROF
+                const long long prof_it0 = clock64();
+#endif
                 const mask_t mA = mL | mU;
                 const int m = __popcll(mA);
                 const bool dual = 2 * m <= n;                     // row-uniform: the smaller side
                 const mask_t mC = busy ? (dual ? mA : (~mA & nmask)) : 0ull;
                 const int c = __popcll(mC);
-                int cw = c;                                      // wave maximum: uniform loop bound
-                if (LPI == 16) { cw = max(cw, __shfl_xor(cw, 16)); cw = max(cw, __shfl_xor(cw, 32)); }
-                cw = __builtin_amdgcn_readfirstlane(cw);
+                int cw;                                          // wave maximum: uniform loop bound (c is row-uniform: one lane per row)
+                if constexpr (LPI == 16)
+                    cw = max(max(__builtin_amdgcn_readlane(c, 0), __builtin_amdgcn_readlane(c, 16)),
+                             max(__builtin_amdgcn_readlane(c, 32), __builtin_amdgcn_readlane(c, 48)));
+                else cw = __builtin_amdgcn_readfirstlane(c);
                 const bool any_primal = __ballot(busy && !dual) != 0ull;
+                if constexpr (LPI == 16) {
+                    if (!any_primal) {
+                        // ---- every busy instance of the wavefront is on the dual side: W_AA lam = r_A, v_F = v_unc,F - W_FA lam ----
+                        // Nothing but the compacted list and right-hand side goes through LDS.  Lane k < c holds unknown k (row
+                        // la_k = list[k]); the column indices of the gathered system and of W_FA reach the other lanes as DPP row
+                        // broadcasts of la_k, the multipliers as the DPP operand of the product, the released bounds as a rotate-OR.
+                        const unsigned mC32 = (unsigned)mC, mL32 = (unsigned)mL, mA32 = (unsigned)mA;
+#pragma unroll
+                        for (int s = 0; s < RB; ++s) {                           // (predicated stores go to the dummy slot)
+                            const unsigned bit = 1u << rw[s];
+                            const bool on = vrow[s] && (mC32 & bit);
+                            const int rk = __popc(mC32 & (bit - 1u));
+                            const double sg = (mL32 & bit) ? -1.0 : 1.0;
+                            list[on ? rk : (C::oD - C::oL) * 2] = rw[s];
+                            rL[on ? rk : C::oD - C::oR] = __builtin_fma(-sg, h[s], vu[s]);
+                        }
+                        __syncthreads();
+                        const bool mine = i < c;
+                        const int la = mine ? list[i] : 0;
+                        double rhs = mine ? rL[i] : 0.0;
+                        const int tla = PACKED ? la * (la + 1) / 2 : la * LDW;
+                        auto widx = [&](int ra, int ta, int lb, int tlb) -> int {   // element (ra, lb) of W; ta / tlb: tri (packed) or row base
+                            if constexpr (PACKED) return max(ta, tlb) + min(ra, lb);
+                            else return ta + lb;
+                        };
+                        double S[CS];
+                        static_for<CS / 4>([&](auto bgc) {
+                            constexpr int bg = decltype(bgc)::value;
+#pragma unroll
+                            for (int bb = 4 * bg; bb < 4 * bg + 4; ++bb) S[bb] = (bb == i) ? 1.0 : 0.0;
+                            if (4 * bg < cw) {                                   // uniform
+                                static_for<4>([&](auto bc) {
+                                    constexpr int bb = 4 * bg + decltype(bc)::value;
+                                    const int lb = rowb_i(la, bb), tlb = PACKED ? rowb_i(tla, bb) : 0;
+                                    const double val = Wp[widx(la, tla, lb, tlb)];
+                                    S[bb] = mine ? val : S[bb];                  // lanes without an unknown keep a row of the identity
+                                });
+                            }
+                        });
+                        bool ok = true;
+                        static_for<CS>([&](auto kc) {
+                            constexpr int k = decltype(kc)::value;
+                            if (k < cw) {
+                                isettle<LPI>(S[k]);
+                                const double d = ibcast<LPI>(S[k], k);
+                                ok = ok && (d > 0.0);
+                                const double inv = frcp(d);
+                                const double g = (i == k) ? (inv - 1.0) : -S[k] * inv;
+#pragma unroll
+                                for (int jg = 0; jg < CS / 4; ++jg) {
+                                    if (4 * jg + 3 > k && 4 * jg < cw) {
+                                        if (4 * jg > k) ifmac_self4<LPI>(&S[4 * jg], g, k);
+                                        else {
+#pragma unroll
+                                            for (int j = 4 * jg; j < 4 * jg + 4; ++j)
+                                                if (j > k) ifmac_self<LPI>(S[j], g, k);
+                                        }
+                                    }
+                                }
+                                ifmac_self<LPI>(rhs, g, k);
+                            }
+                        });
+                        const bool rowfail = iballot<LPI>(!ok, q) != 0;
+                        // t = W_FA lam on my rows: column la_k of W times the multiplier of lane k
+                        double tt[RB];
+#pragma unroll
+                        for (int s = 0; s < RB; ++s) tt[s] = 0.0;
+                        const int trow[2] = {PACKED ? tri[0] : rw[0] * LDW, RB > 1 ? (PACKED ? tri[RB - 1] : rw[RB - 1] * LDW) : 0};
+                        static_for<CS / 4>([&](auto kgc) {
+                            constexpr int kg = decltype(kgc)::value;
+                            if (4 * kg < cw) {                                   // uniform
+                                double wv[4][RB];
+                                static_for<4>([&](auto kc) {
+                                    constexpr int kk = decltype(kc)::value;
+                                    const int lk = rowb_i(la, 4 * kg + kk), tlk = PACKED ? rowb_i(tla, 4 * kg + kk) : 0;
+#pragma unroll
+                                    for (int s = 0; s < RB; ++s) wv[kk][s] = Wp[vrow[s] ? widx(rw[s], trow[s], lk, tlk) : 0];
+                                });
+                                static_for<4>([&](auto kc) {
+                                    constexpr int kk = decltype(kc)::value;
+#pragma unroll
+                                    for (int s = 0; s < RB; ++s) fmac_rowb(tt[s], rhs, wv[kk][s], 4 * kg + kk);
+                                });
+                            }
+                        });
+                        // the multipliers decide in their own lanes which bounds stay: rows la_k whose multiplier keeps its sign
+                        const unsigned lhi = (unsigned)__double2hiint(rhs) & 0x7fffffffu;
+                        const double tol = 1e-10 * __hiloint2double((int)row_umax(mine ? lhi : 0u), 0);
+                        const bool isL = (mL32 >> la) & 1u;
+                        const unsigned keepL = (mine && isL && rhs <= tol) ? (1u << la) : 0u;
+                        const unsigned keepU = (mine && !isL && rhs >= -tol) ? (1u << la) : 0u;
+                        unsigned nL32 = row_or(keepL), nU32 = row_or(keepU);
+                        bool nf = false;
+#pragma unroll
+                        for (int s = 0; s < RB; ++s) {
+                            const unsigned bit = 1u << rw[s];
+                            const bool act = vrow[s] && (mA32 & bit);
+                            const double sg = (mL32 & bit) ? -1.0 : 1.0;
+                            const double nv = act ? sg * h[s] : vu[s] - tt[s];
+                            v[s] = busy ? nv : v[s];
+                            const bool fr = vrow[s] && !act;
+                            nL32 |= (unsigned)(iballot<LPI>(fr && v[s] < -h[s] * (1.0 + 1e-12), q) << (LPI * s));
+                            nU32 |= (unsigned)(iballot<LPI>(fr && v[s] > h[s] * (1.0 + 1e-12), q) << (LPI * s));
+                            nf = nf || (vrow[s] && !(fabs(v[s]) < 1e300));
+                        }
+                        const bool rownf = iballot<LPI>(nf || (mine && !(fabs(rhs) < 1e300)), q) != 0;
+#ifdef LQMPC_R16_PROF
+                        prof_wit += 1; prof_fast += 1; prof_ph[7] += clock64() - prof_it0;
+#endif
+                        if (busy) {
+                            iters += 1;
+                            if (rowfail || rownf) { failed = true; busy = false; }
+                            else if ((mask_t)nL32 == mL && (mask_t)nU32 == mU) busy = false;
+                            else { mL = nL32; mU = nU32; }
+                        }
+                        __syncthreads();
+                        if (__ballot(busy) == 0ull) break;
+                        continue;
+                    }
+                }
                 // publish v_unc, r = v_unc - s h on the active rows (0 elsewhere), the list of the chosen side
 #pragma unroll
                 for (int s = 0; s < RB; ++s) {
@@ -590,16 +744,37 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 const ldsd *Mx = dual ? Wp : Pp;
                 const int la = (i < c) ? list[i] : 0, tla = la * (la + 1) / 2;
                 double S[CS], rhs;
+                if constexpr (LPI == 16) {
+                    // the column indices reach the lanes as DPP broadcasts of la: no dependent LDS reads, every load of a group in flight
+                    // at once.  Only lanes without an unknown need the identity: columns beyond c meet zeros only (see the dual-only path).
+                    const int tla2 = PACKED ? tla : la * LDW;
+                    static_for<CS / 4>([&](auto bgc) {
+                        constexpr int bg = decltype(bgc)::value;
 #pragma unroll
-                for (int bg = 0; bg < CS / 4; ++bg) {            // columns in groups of four: one uniform test per group
+                        for (int bb = 4 * bg; bb < 4 * bg + 4; ++bb) S[bb] = (bb == i) ? 1.0 : 0.0;
+                        if (4 * bg < cw) {
+                            static_for<4>([&](auto bc) {
+                                constexpr int bb = 4 * bg + decltype(bc)::value;
+                                const int lb = rowb_i(la, bb), tlb = PACKED ? rowb_i(tla2, bb) : 0;
+                                int idx;
+                                if constexpr (PACKED) idx = max(tla2, tlb) + min(la, lb); else idx = tla2 + lb;
+                                const double val = Mx[idx];
+                                S[bb] = (i < c) ? val : S[bb];
+                            });
+                        }
+                    });
+                } else {
 #pragma unroll
-                    for (int bb = 4 * bg; bb < 4 * bg + 4; ++bb) S[bb] = (bb == i) ? 1.0 : 0.0;
-                    if (4 * bg < cw) {
+                    for (int bg = 0; bg < CS / 4; ++bg) {            // columns in groups of four: one uniform test per group
 #pragma unroll
-                        for (int bb = 4 * bg; bb < 4 * bg + 4; ++bb) {
-                            const int lb = (bb < c) ? list[bb] : 0;
-                            const double val = Mx[ad2(la, lb)];
-                            if (i < c && bb < c) S[bb] = val;
+                        for (int bb = 4 * bg; bb < 4 * bg + 4; ++bb) S[bb] = (bb == i) ? 1.0 : 0.0;
+                        if (4 * bg < cw) {
+#pragma unroll
+                            for (int bb = 4 * bg; bb < 4 * bg + 4; ++bb) {
+                                const int lb = (bb < c) ? list[bb] : 0;
+                                const double val = Mx[ad2(la, lb)];
+                                if (i < c && bb < c) S[bb] = val;
+                            }
                         }
                     }
                 }
@@ -680,7 +855,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 }
                 const bool rownf = iballot<LPI>(nf, q) != 0;
 #ifdef LQMPC_R16_PROF
-                prof_wit += 1;
+                prof_wit += 1; prof_slow += 1; prof_slowt += clock64() - prof_it0;
 #endif
                 if (busy) {
                     iters += 1;
@@ -865,6 +1040,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         for (int t = 0; t < p.T; ++t) {
             double v[RB], u[NU], xn[NX];
 #ifdef LQMPC_R16_PROF
+            if (t == 1) { RPROF_ADD(27, clock64() - prof_ts); RPROF_ADD(28, prof_wit); RPROF_ADD(29, prof_slow); }
             if (t > 0) {
                 const long long d_ = clock64() - prof_ts;
                 if (prof_wit) { prof_acc[1] += d_; prof_acc[3] += 1; prof_acc[4] += prof_wit; } else { prof_acc[0] += d_; prof_acc[2] += 1; }
@@ -872,7 +1048,23 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             prof_ts = clock64();
             prof_wit = 0;
 #endif
-            qp(x, v);
+            // most steps of most wavefronts: the unconstrained minimiser of every instance of the wavefront is inside its box --
+            // one compare per row slot and one wave-wide test, none of the mask bookkeeping of qp()
+            bool inside = false;
+            if constexpr (LPI == 16) {
+                bool out = false;
+#pragma unroll
+                for (int s = 0; s < RB; ++s) {
+                    double acc = vr[s];
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) acc = __builtin_fma(G[s][a], x[a], acc);
+                    v[s] = acc;
+                    out = out || (vrow[s] && !(fabs(acc) <= h[s]));       // (not <=: a NaN counts as outside and takes the general path)
+                }
+                inside = __ballot(out) == 0ull;
+            }
+            if (inside) { pL = 0; pU = 0; }
+            else qp(x, v);
             const double um = fmin(fmax(v[0], -h[0]), h[0]) + ctr[0];     // the input of my first row: u_i in lane i < NU
             stage_input(v, 0, u);
             double xm = 0.0, qx = 0.0, ru = 0.0;
@@ -910,7 +1102,11 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #ifdef LQMPC_R16_PROF
         for (int k_ = 0; k_ < 5; ++k_) RPROF_ADD(8 + k_, prof_acc[k_]);
 #endif
-        RPROF_ADD(14, clock64() - prof_t0); RPROF_ADD(15, 1);
+        RPROF_ADD(14, clock64() - prof_t0); RPROF_ADD(15, 1); RPROF_ADD(16, prof_slow);
+#ifdef LQMPC_R16_PROF
+        for (int k_ = 0; k_ < 8; ++k_) RPROF_ADD(17 + k_, prof_ph[k_]);
+        RPROF_ADD(25, prof_slowt); RPROF_ADD(26, prof_fast);
+#endif
         if (writer) p.JT[b] = cost;
     }
     if (writer) {
