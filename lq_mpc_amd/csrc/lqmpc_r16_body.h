@@ -1051,7 +1051,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             // most steps of most wavefronts: the unconstrained minimiser of every instance of the wavefront is inside its box --
             // one compare per row slot and one wave-wide test, none of the mask bookkeeping of qp()
             bool inside = false;
-            if constexpr (LPI == 16) {
+            {
                 bool out = false;
 #pragma unroll
                 for (int s = 0; s < RB; ++s) {

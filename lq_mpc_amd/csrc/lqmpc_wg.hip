@@ -263,9 +263,15 @@ struct Wg {
     // suffix sum along the stage diagonals.
     __device__ __forceinline__ void setup(long long b)
     {
+        stage(b);
+        condense_P();
+        finish_condensed();
+    }
+
+    __device__ __forceinline__ void stage(long long b)
+    {
         const long long Bsz = p.Bsz;
-        PROF_START;
-        ldsd *Ma = lds + o.Linv, *X = lds + o.X, *Xf = lds + o.Xf, *Lam = lds + o.Lam;
+        ldsd *Ma = lds + o.Linv, *X = lds + o.X;
         ldsd *Am = lds + o.AB, *Bm = Am + nx * nx;
         {   // stage the shared block, the plant and the model
             ldsd *S = lds + o.SH;
@@ -280,7 +286,18 @@ struct Wg {
                 for (int e = t; e < nx * nu; e += THREADS) S[p.so.Bt + e] = p.Bt[(long long)e * Bsz + b];
             }
         }
+        __syncthreads();
+    }
+
+    // P = 2 (Gamma'Qbar Gamma + Rbar) into the K region and into the registers
+    __device__ __forceinline__ void condense_P()
+    {
+        PROF_START;
+        ldsd *Ma = lds + o.Linv, *X = lds + o.X, *Xf = lds + o.Xf;
+        ldsd *Am = lds + o.AB, *Bm = Am + nx * nx;
         const ldsd *sh = shd();
+        for (int e = t; e < nb * BLK; e += THREADS) { Ma[e] = 0.0; X[e] = 0.0; }
+        __syncthreads();
         // The powers of A by doubling, A^(L+i) = A^L A^i for i = 1..L (log2 N dependent levels instead of N: every level is
         // a barrier and a latency-bound dot product with one wavefront per SIMD), then all M_m = A^m B at once.
         {
@@ -375,6 +392,51 @@ struct Wg {
             const int e = t + THREADS * m;
             preg[m] = (e < total) ? lds[o.K + e] : 0.0;
         }
+        __syncthreads();
+    }
+
+    // constant part of the linear term from the references: gq = 2 gref, with
+    //   d_r = -xref_r,  lam_r = Q_r d_r + A' lam_{r+1},  gref_r = B' lam_r - R uref_r   (columns r = 0..N-1 <-> x_{r+1}, u_r)
+    __device__ __forceinline__ void ref_linear_term(ldsd *gq)
+    {
+        ldsd *Lam = lds + o.Lam;
+        ldsd *Am = lds + o.AB, *Bm = Am + nx * nx;
+        const ldsd *sh = shd();
+        if (t < np) gq[t] = 0.0;
+        if (p.has_ref) {
+            const ldsd *xr = sh + p.so.xref, *ur = sh + p.so.uref;
+            ldsd *lam = Lam, *lam2 = Lam + nx;
+            if (t < nx) lam[t] = 0.0;
+            for (int r = N - 1; r >= 0; --r) {
+                const ldsd *Qr = sh + ((r < N - 1) ? p.so.Q : p.so.P);
+                __syncthreads();
+                if (t < nx) {
+                    double a = 0.0;
+                    for (int y = 0; y < nx; ++y) a = __builtin_fma(Qr[t * nx + y], -xr[y * N + r], a);
+                    for (int y = 0; y < nx; ++y) a = __builtin_fma(Am[y * nx + t], lam[y], a);
+                    lam2[t] = a;
+                }
+                __syncthreads();
+                if (t < nx) lam[t] = lam2[t];
+                if (t < nu) {
+                    double a = 0.0;
+                    for (int x = 0; x < nx; ++x) a = __builtin_fma(Bm[x * nu + t], lam2[x], a);
+                    for (int j = 0; j < nu; ++j) a = __builtin_fma(-sh[p.so.R + t * nu + j], ur[j * N + r], a);
+                    gq[r * nu + t] = 2.0 * a;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // Fq, the constant linear term, W = P^-1 by Cholesky, [G | v_r] = -W [Fq | qr]   (K holds P on entry)
+    __device__ __forceinline__ void finish_condensed()
+    {
+        PROF_START;
+        ldsd *X = lds + o.X, *Xf = lds + o.Xf, *Lam = lds + o.Lam;
+        ldsd *Am = lds + o.AB, *Bm = Am + nx * nx;
+        const ldsd *sh = shd();
+        const int wave = t >> 6;
         // Fq = 2 Gamma' Qbar Phi by the costate recursion on matrices:
         //   Lam_N = P_T A^N,  Lam_k = Q A^k + A' Lam_{k+1},  Fq block row bi = 2 B' Lam_{bi+1}
         // (rows of Fq are written one step behind the recursion by a second group of threads)
@@ -403,34 +465,9 @@ struct Wg {
             }
         }
         PROF(3);
-        // constant part of the linear term: qr = 2 gref + P centre, with
-        //   d_r = -xref_r,  lam_r = Q_r d_r + A' lam_{r+1},  gref_r = B' lam_r - R uref_r   (columns r = 0..N-1 <-> x_{r+1}, u_r)
+        // constant part of the linear term: qr = 2 gref + P centre
         ldsd *gq = lds + o.vw;
-        if (t < np) gq[t] = 0.0;
-        if (p.has_ref) {
-            const ldsd *xr = sh + p.so.xref, *ur = sh + p.so.uref;
-            ldsd *lam = Lam, *lam2 = Lam + nx;
-            if (t < nx) lam[t] = 0.0;
-            for (int r = N - 1; r >= 0; --r) {
-                const ldsd *Qr = sh + ((r < N - 1) ? p.so.Q : p.so.P);
-                __syncthreads();
-                if (t < nx) {
-                    double a = 0.0;
-                    for (int y = 0; y < nx; ++y) a = __builtin_fma(Qr[t * nx + y], -xr[y * N + r], a);
-                    for (int y = 0; y < nx; ++y) a = __builtin_fma(Am[y * nx + t], lam[y], a);
-                    lam2[t] = a;
-                }
-                __syncthreads();
-                if (t < nx) lam[t] = lam2[t];
-                if (t < nu) {
-                    double a = 0.0;
-                    for (int x = 0; x < nx; ++x) a = __builtin_fma(Bm[x * nu + t], lam2[x], a);
-                    for (int j = 0; j < nu; ++j) a = __builtin_fma(-sh[p.so.R + t * nu + j], ur[j * N + r], a);
-                    gq[r * nu + t] = 2.0 * a;
-                }
-            }
-            __syncthreads();
-        }
+        ref_linear_term(gq);
         double qr = (t < np) ? gq[t] : 0.0;
         if (block_any(own && ctr != 0.0)) {
             if (t < np) gq[t] = own ? ctr : 0.0;
@@ -770,6 +807,45 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
         if (p.X && t < nx) p.X[((long long)t * (p.T + 1)) * Bsz + b] = xs[t];
     }
     for (int step = 0; step < nsteps; ++step) {
+        if (mode == MODE_ROLLOUT) {
+            // Interior steps, one barrier each (most steps of most rollouts: 27 % of the C5 launch went into them when each took
+            // the seven barriers of solve_qp + publish_v + the plant update).  The next state is computed SPECULATIVELY from the
+            // unclipped minimiser into the other half of the state buffer while the box test is still in flight: the test's
+            // workgroup-wide OR is the one barrier, and it also publishes the state.  A step that fails the test (or holds a
+            // NaN) leaves everything as it was and takes the general path below.
+            ldsd *uw = lds + w.o.vw;
+            ldsd *cur = xs, *nxt = xs + nx;                           // the state ping-pongs between the two halves: one barrier per step
+            for (;;) {
+                const double vu = w.own ? ldot(lds + w.o.G + t, w.np, cur, 1, nx, w.vr) : 0.0;
+                const bool out = w.own && !(fabs(vu) <= w.h);
+                if (t < nu) uw[t] = vu + w.ctr;                       // same wavefront as the readers below: LDS keeps the order
+                double xn = 0.0;
+                if (t < nx) {
+                    xn = ldot(sh + p.so.Bt + t * nu, 1, uw, 1, nu, ldot(sh + p.so.At + t * nx, 1, cur, 1, nx));
+                    nxt[t] = xn;
+                }
+                if (__syncthreads_or(out ? 1 : 0)) break;
+                // inside the box: commit the step (costs, trajectories); the next round writes the half nobody reads any more
+                if (t < nx) {
+                    cost = __builtin_fma(xn, ldot(sh + p.so.Q + t * nx, 1, nxt, 1, nx), cost);
+                    if (p.X) p.X[((long long)t * (p.T + 1) + step + 1) * Bsz + b] = xn;
+                }
+                if (t < nu) {
+                    const double ut = uw[t];
+                    cost = __builtin_fma(ut, ldot(sh + p.so.R + t * nu, 1, uw, 1, nu), cost);
+                    if (p.U) p.U[((long long)t * p.T + step) * Bsz + b] = ut;
+                }
+                ldsd *sw = cur; cur = nxt; nxt = sw;
+                w.act_prev = 0.0;
+                if (++step >= nsteps) break;
+            }
+            if (cur != xs) {                                          // uniform: the general path expects the state in the first half
+                __syncthreads();
+                if (t < nx) xs[t] = cur[t];
+                __syncthreads();
+            }
+            if (step >= nsteps) break;
+        }
         if (mode == MODE_MAXVN) {
             __syncthreads();
             if (t < nx) xs[t] = p.sh[p.so.x0s + t * p.K + step];

@@ -6,13 +6,13 @@ from lq_mpc_amd import BatchSolver, synth
 dev = torch.device('cuda', 0)
 s = BatchSolver(0, stream=torch.cuda.current_stream(dev).cuda_stream)
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-b = synth.make_batch(cfg)
+b = synth.make_batch(cfg, Bsz=int(sys.argv[2]) if len(sys.argv) > 2 else None)
 nx, nu, N, Bsz = b['A'].shape[0], b['B'].shape[1], b['N'], b['Bsz']
 dA = torch.from_numpy(b['A']).to(dev); dB = torch.from_numpy(b['B']).to(dev)
 dJ = torch.empty(Bsz, dtype=torch.float64, device=dev); dit = torch.empty(Bsz, dtype=torch.int32, device=dev)
 for name, scale in (('default', 1.0), ('tiny x0', 1e-3)):
     dx0 = torch.from_numpy(b['x0'] * scale).to(dev)
-    for order in (-1, 0):
+    for order in (-1,):
         s.set_options(order=order)
         for T in (1, 2, 8, 30):
             for _ in range(3):

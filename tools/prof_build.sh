@@ -10,3 +10,9 @@ for f in lqmpc_api lqmpc_bounds lqmpc_spec lqmpc_generic lqmpc_wg lqmpc_r16_lat;
     -c "$ROOT/lq_mpc_amd/csrc/lqmpc_r16.hip" -o "$ROOT/build_prof/lqmpc_r16.o"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/build_prof/liblqmpc_prof.so" "$ROOT"/build_prof/*.o
 echo built "$ROOT/build_prof/liblqmpc_prof.so"
+# the workgroup kernel's instrumented build (block 0's phases): build_prof/liblqmpc_wgprof.so
+mkdir -p "$ROOT/build_prof/wg"
+for f in lqmpc_api lqmpc_bounds lqmpc_spec lqmpc_generic lqmpc_r16 lqmpc_r16_lat; do cp "$ROOT/lq_mpc_amd/csrc/$f.o" "$ROOT/build_prof/wg/"; done
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -DLQMPC_WG_PROF -c "$ROOT/lq_mpc_amd/csrc/lqmpc_wg.hip" -o "$ROOT/build_prof/wg/lqmpc_wg.o"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/build_prof/liblqmpc_wgprof.so" "$ROOT"/build_prof/wg/*.o
+echo built "$ROOT/build_prof/liblqmpc_wgprof.so"
