@@ -52,6 +52,13 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+struct HostBuf {                     // pinned host memory (hipHostMalloc) + the event of the last copy that read / wrote it
+    void *p = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool ev_valid = false;
+};
+
 struct lqmpc_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -63,6 +70,10 @@ struct lqmpc_handle {
     bool fail_cleared = false;       // build_order zeroed count and counters in this call already
     DevBuf st2, it2;                 // lqmpc_sweep_batch_dev without a fused kernel: status / iters of the max-V_N pass
     DevBuf stage[12];                // host-flavour staging (inputs and outputs)
+    DevBuf arena;                    // host-flavour staging of small calls: one packed block, one copy each way
+    HostBuf arena_pin;
+    HostBuf shared_pin[2];           // source of the shared block's upload
+    int shared_turn = 0;
     std::vector<double> shared_host; // last uploaded shared block
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const char *last_kernel = "none";
@@ -70,6 +81,25 @@ struct lqmpc_handle {
 };
 
 constexpr size_t FAIL_HDR = 16 + (size_t)lqmpc::ORDER_CELLS * lqmpc::ORDER_PAD;    // ints in front of the hand-back list: its count, the order's counters
+
+static int ensure_host(HostBuf &b, size_t bytes)
+{
+    if (!b.ev) {
+        hipError_t e = hipEventCreateWithFlags(&b.ev, hipEventDisableTiming);
+        if (e != hipSuccess) { b.ev = nullptr; return fail(LQMPC_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
+    }
+    if (bytes <= b.cap) return 0;
+    if (b.p) {
+        if (b.ev_valid) (void)hipEventSynchronize(b.ev);
+        (void)hipHostFree(b.p);
+        b.p = nullptr; b.cap = 0; b.ev_valid = false;
+    }
+    const size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
+    if (e != hipSuccess) { b.p = nullptr; return fail(LQMPC_ERR_ALLOC, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+    b.cap = want;
+    return 0;
+}
 
 static int ensure(lqmpc_handle *h, DevBuf &b, size_t bytes)
 {
@@ -157,6 +187,11 @@ int lqmpc_destroy(lqmpc_handle *h)
     if (h->ws.p) (void)hipFree(h->ws.p);
     for (DevBuf *b : {&h->key, &h->perm, &h->rec, &h->fail, &h->st2, &h->it2}) if (b->p) (void)hipFree(b->p);
     for (auto &b : h->stage) if (b.p) (void)hipFree(b.p);
+    if (h->arena.p) (void)hipFree(h->arena.p);
+    for (HostBuf *b : {&h->arena_pin, &h->shared_pin[0], &h->shared_pin[1]}) {
+        if (b->p) (void)hipHostFree(b->p);
+        if (b->ev) (void)hipEventDestroy(b->ev);
+    }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -315,9 +350,18 @@ static int prepare(lqmpc_handle *h, const Call &c, KParams &p)
     rc = ensure(h, h->shared, sh.size() * sizeof(double));
     if (rc) return rc;
     if (sh != h->shared_host) {
-        // the device copy may still be read by an earlier launch on this stream: order behind it
-        HIP_TRY(hipMemcpyAsync(h->shared.p, sh.data(), sh.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        // The device copy may still be read by an earlier launch on this stream: the copy is ordered behind it by the stream.  No
+        // host-side wait: the source is pinned memory owned by the handle (two buffers taken in turn, so that the copy of this call
+        // cannot be overwritten by the next call's packing while it is still in flight).
+        const size_t bytes = sh.size() * sizeof(double);
+        HostBuf &hb = h->shared_pin[h->shared_turn ^= 1];
+        int rc2 = ensure_host(hb, bytes);
+        if (rc2) return rc2;
+        if (hb.ev_valid) HIP_TRY(hipEventSynchronize(hb.ev));       // (two calls back: long done, costs nothing)
+        memcpy(hb.p, sh.data(), bytes);
+        HIP_TRY(hipMemcpyAsync(h->shared.p, hb.p, bytes, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipEventRecord(hb.ev, h->stream));
+        hb.ev_valid = true;
         h->shared_host.swap(sh);
     }
     p.nx = nx; p.nu = nu; p.N = N; p.n = N * nu;
@@ -623,14 +667,62 @@ int lqmpc_sweep_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, i
 
 // ---- host-buffer flavours: stage in, run, stage out ----
 namespace {
+// Small calls (the reference's own call shape is ONE instance per solve(), utils_class.py:269) are dominated by the number of
+// copies, not their size: below PACK_LIMIT bytes in total every array of the call is packed into one pinned host block and one
+// device block -- one copy in, one copy out.  Larger calls copy array by array straight from / to the caller's buffers.
+constexpr size_t PACK_LIMIT = 256 * 1024;
 struct Stager {
     lqmpc_handle *h;
     int slot = 0;
     int rc = 0;
+    bool packed = false;
+    size_t off = 0, in_end = 0;
+    struct Out { void *host; size_t off, bytes; } outs[12];
+    int nout = 0;
+    // total: an upper bound of the bytes of all in() / out() arrays of the call
+    void begin(size_t total)
+    {
+        total += 24 * 256;
+        if (total > PACK_LIMIT) return;
+        rc = ensure(h, h->arena, total);
+        if (!rc) rc = ensure_host(h->arena_pin, total);
+        if (rc) return;
+        if (h->arena_pin.ev_valid) { (void)hipEventSynchronize(h->arena_pin.ev); h->arena_pin.ev_valid = false; }
+        packed = true;
+    }
+    size_t take(size_t bytes) { const size_t o = off; off = (off + bytes + 255) / 256 * 256; return o; }
+    // after the last in(): the one copy of the inputs
+    void upload()
+    {
+        if (rc || !packed) return;
+        if (nout == 0) in_end = off;                              // (the first out() froze it otherwise)
+        if (in_end == 0) return;
+        hipError_t e = hipMemcpyAsync(h->arena.p, h->arena_pin.p, in_end, hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) rc = fail(LQMPC_ERR_HIP, std::string("H2D: ") + hipGetErrorString(e));
+    }
+    // after the launches: the one copy of the outputs, the wait, and the hand-over to the caller's arrays
+    int finish()
+    {
+        if (rc) return rc;
+        if (packed && nout > 0) {
+            hipError_t e = hipMemcpyAsync((char *)h->arena_pin.p + in_end, (char *)h->arena.p + in_end, off - in_end, hipMemcpyDeviceToHost, h->stream);
+            if (e != hipSuccess) return fail(LQMPC_ERR_HIP, std::string("D2H: ") + hipGetErrorString(e));
+        }
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) return fail(LQMPC_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+        if (packed)
+            for (int k = 0; k < nout; ++k) memcpy(outs[k].host, (char *)h->arena_pin.p + outs[k].off, outs[k].bytes);
+        return 0;
+    }
     template <typename T>
     T *in(const T *host, size_t count)
     {
         if (rc || !host) return nullptr;
+        if (packed) {
+            const size_t o = take(count * sizeof(T));
+            memcpy((char *)h->arena_pin.p + o, host, count * sizeof(T));
+            return (T *)((char *)h->arena.p + o);
+        }
         DevBuf &b = h->stage[slot++];
         rc = ensure(h, b, count * sizeof(T));
         if (rc) return nullptr;
@@ -642,6 +734,12 @@ struct Stager {
     T *out(T *host, size_t count)
     {
         if (rc || !host) return nullptr;
+        if (packed) {
+            if (nout == 0 && in_end == 0) in_end = off;           // (a call without inputs to upload)
+            const size_t o = take(count * sizeof(T));
+            outs[nout++] = Out{host, o, count * sizeof(T)};
+            return (T *)((char *)h->arena.p + o);
+        }
         DevBuf &b = h->stage[slot++];
         rc = ensure(h, b, count * sizeof(T));
         return rc ? nullptr : (T *)b.p;
@@ -649,7 +747,7 @@ struct Stager {
     template <typename T>
     void back(T *host, const T *dev, size_t count)
     {
-        if (rc || !host) return;
+        if (rc || !host || packed) return;                        // packed: finish() copies everything back at once
         hipError_t e = hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, h->stream);
         if (e != hipSuccess) rc = fail(LQMPC_ERR_HIP, std::string("D2H: ") + hipGetErrorString(e));
     }
@@ -669,16 +767,16 @@ int lqmpc_solve_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, const
     HIP_TRY(hipSetDevice(h->device));
     Stager s{h};
     const size_t b = (size_t)Bsz;
+    s.begin(b * 8 * (size_t)(nx * nx + nx * nu + nx + nu + 2));
     const double *dA = s.in(A, b * nx * nx), *dB = s.in(B, b * nx * nu), *dx0 = s.in(x0, b * nx);
     double *du0 = s.out(u0, b * nu), *dVN = s.out(VN, b);
     int32_t *dst = s.out(status, b), *dit = s.out(iters, b);
+    s.upload();
     if (s.rc) return s.rc;
     rc = lqmpc_solve_batch_dev(h, nx, nu, N, Bsz, dA, dB, Q, R, P, lb, ub, dx0, x_ref, u_ref, du0, dVN, dst, dit);
     if (rc) return rc;
     s.back(u0, du0, b * nu); s.back(VN, dVN, b); s.back(status, dst, b); s.back(iters, dit, b);
-    if (s.rc) return s.rc;
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    return 0;
+    return s.finish();
 }
 
 int lqmpc_rollout_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int T, const double *A, const double *B,
@@ -694,20 +792,20 @@ int lqmpc_rollout_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int
     HIP_TRY(hipSetDevice(h->device));
     Stager s{h};
     const size_t b = (size_t)Bsz;
+    s.begin(b * 8 * (size_t)(2 * (nx * nx + nx * nu) + nx + 2 + (X ? nx * (T + 1) : 0) + (U ? nu * T : 0)));
     const double *dA = s.in(A, b * nx * nx), *dB = s.in(B, b * nx * nu), *dx0 = s.in(x0, b * nx);
     const double *dAt = A_true, *dBt = B_true;
     if (true_per_instance) { dAt = s.in(A_true, b * nx * nx); dBt = s.in(B_true, b * nx * nu); }
     double *dJT = s.out(JT, b), *dX = s.out(X, b * nx * (T + 1)), *dU = s.out(U, b * nu * T);
     int32_t *dst = s.out(status, b), *dit = s.out(iters, b);
+    s.upload();
     if (s.rc) return s.rc;
     rc = lqmpc_rollout_batch_dev(h, nx, nu, N, Bsz, T, dA, dB, Q, R, P, lb, ub, dx0, dAt, dBt, true_per_instance, x_ref,
                                  u_ref, dJT, dX, dU, dst, dit);
     if (rc) return rc;
     s.back(JT, dJT, b); s.back(X, dX, b * nx * (T + 1)); s.back(U, dU, b * nu * T);
     s.back(status, dst, b); s.back(iters, dit, b);
-    if (s.rc) return s.rc;
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    return 0;
+    return s.finish();
 }
 
 int lqmpc_max_vn_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int K, const double *A, const double *B,
@@ -721,16 +819,16 @@ int lqmpc_max_vn_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int 
     HIP_TRY(hipSetDevice(h->device));
     Stager s{h};
     const size_t b = (size_t)Bsz;
+    s.begin(b * 8 * (size_t)(nx * nx + nx * nu + 2));
     const double *dA = s.in(A, b * nx * nx), *dB = s.in(B, b * nx * nu);
     double *dMV = s.out(MV, b);
     int32_t *dst = s.out(status, b), *dit = s.out(iters, b);
+    s.upload();
     if (s.rc) return s.rc;
     rc = lqmpc_max_vn_batch_dev(h, nx, nu, N, Bsz, K, dA, dB, Q, R, P, lb, ub, x0s, x_ref, u_ref, dMV, dst, dit);
     if (rc) return rc;
     s.back(MV, dMV, b); s.back(status, dst, b); s.back(iters, dit, b);
-    if (s.rc) return s.rc;
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    return 0;
+    return s.finish();
 }
 
 int lqmpc_sweep_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int T, int K, const double *A, const double *B,
@@ -744,19 +842,19 @@ int lqmpc_sweep_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int T
     HIP_TRY(hipSetDevice(h->device));
     Stager s{h};
     const size_t b = (size_t)Bsz;
+    s.begin(b * 8 * (size_t)(2 * (nx * nx + nx * nu) + nx + 3));
     const double *dA = s.in(A, b * nx * nx), *dB = s.in(B, b * nx * nu), *dx0 = s.in(x0, b * nx);
     const double *dAt = A_true, *dBt = B_true;
     if (true_per_instance) { dAt = s.in(A_true, b * nx * nx); dBt = s.in(B_true, b * nx * nu); }
     double *dJT = s.out(JT, b), *dMV = s.out(MV, b);
     int32_t *dst = s.out(status, b), *dit = s.out(iters, b);
+    s.upload();
     if (s.rc) return s.rc;
     rc = lqmpc_sweep_batch_dev(h, nx, nu, N, Bsz, T, K, dA, dB, Q, R, P, lb, ub, dx0, x0s, dAt, dBt, true_per_instance, x_ref, u_ref,
                                dJT, dMV, dst, dit);
     if (rc) return rc;
     s.back(JT, dJT, b); s.back(MV, dMV, b); s.back(status, dst, b); s.back(iters, dit, b);
-    if (s.rc) return s.rc;
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    return 0;
+    return s.finish();
 }
 
 // ---- the bound coefficients of data_generation: lqmpc_bounds.hip ----
@@ -845,9 +943,7 @@ int lqmpc_bounds_batch(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, cons
     if (rc) return rc;
     s.back(K, dK, b * nu * nx); s.back(alpha, dal, b); s.back(beta, dbe, b); s.back(xi, dxi, b); s.back(eta, det, b);
     s.back(bound, dbd, b); s.back(eps, dep, b); s.back(aux, dax, b * 8); s.back(status, dst, b);
-    if (s.rc) return s.rc;
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    return 0;
+    return s.finish();
 }
 
 int lqmpc_timer_begin(lqmpc_handle *h)
