@@ -344,6 +344,27 @@ def main():
                               "kernel": s.last_kernel(),
                               "workload": "lqmpc_sweep_batch_dev: max V_N over 8 level-set points + the T-step rollout per system "
                                           "(utils_class.py:813-833), one launch"}
+        # the rest of data_generation per system (utils_class.py:837-859): dlqr + energy_decreasing + energy_bound on the GPU
+        if args.config != 1:
+            dMV = torch.full((Bsz,), 0.5, dtype=torch.float64, device=dev)
+            dlev = torch.full((Bsz,), 5e-3, dtype=torch.float64, device=dev)
+            outs = [torch.empty(Bsz, dtype=torch.float64, device=dev) for _ in range(5)]
+            dstb = torch.empty(Bsz, dtype=torch.int32, device=dev)
+            xb, pb = np.ascontiguousarray(b["x0"][:, 0]), np.array([0.1, 1.0, 0.6])
+
+            def launch_bounds():
+                s.bounds_batch_dev(nx, nu, N, Bsz, dA, dB, b["Q"], b["R"], b["lb"], b["ub"], dlev, dlev, dMV, xb, pb, 1.0,
+                                   dalpha=outs[0], dbeta=outs[1], dxi=outs[2], deta=outs[3], dbound=outs[4], dstatus=dstb)
+            for _ in range(2):
+                launch_bounds()
+            s.timer_begin()
+            for _ in range(3):
+                launch_bounds()
+            msb = s.timer_end() / 3
+            extra["bounds"] = {"value": round(Bsz / (msb * 1e-3), 1), "unit": "systems/s", "kernel_ms_per_launch": round(msb, 4),
+                               "dlqr_not_converged": int((dstb == 1).sum().item()) + int((dstb == 2).sum().item()),
+                               "workload": "lqmpc_bounds_batch_dev: dlqr (doubling) + local radius + stability numbers + alpha/beta/xi/eta/bound "
+                                           "per system (utils_class.py:837-859), one instance per lane, Jacobi sweeps on N n_u x N n_u matrices"}
         # single-call latency: the reference's call shape is ONE instance per solve() (utils_class.py:269)
         lat = {}
         for m in (1, 64, 4096):
