@@ -729,6 +729,154 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                         __syncthreads();
                         if (__ballot(busy) == 0ull) break;
                         continue;
+                    } else {
+                        // ---- mixed wavefront: some busy instance is on the primal side (|A| > n/2: P_FF dlt = (P r)_F,
+                        // v_F = v_unc,F + dlt, gradient on A = P_AF dlt - (P r)_A with r = v_unc - s h on A, 0 on F) ----
+                        // Same skeleton as the dual-only path, the side chosen per instance: the matrix is P instead of W, the
+                        // right-hand side and the gradient need z = P r (one row product, r through LDS by row), and the
+                        // solution goes back to its rows through LDS once.
+                        const unsigned mC32 = (unsigned)mC, mL32 = (unsigned)mL, mA32 = (unsigned)mA, mU32 = (unsigned)mU;
+                        double rr[RB], z[RB];
+#pragma unroll
+                        for (int s = 0; s < RB; ++s) {
+                            const unsigned bit = 1u << rw[s];
+                            const bool act = vrow[s] && (mA32 & bit);
+                            const double sg = (mL32 & bit) ? -1.0 : 1.0;
+                            rr[s] = act ? __builtin_fma(-sg, h[s], vu[s]) : 0.0;
+                            rL[rw[s]] = rr[s];
+                            z[s] = 0.0;
+                        }
+                        __syncthreads();
+#pragma unroll
+                        for (int j = 0; j < n; ++j) {
+                            const double rj = rL[j];
+#pragma unroll
+                            for (int s = 0; s < RB; ++s) z[s] = __builtin_fma(Pp[vrow[s] ? ad(rw[s], tri[s], j) : 0], rj, z[s]);
+                        }
+#pragma unroll
+                        for (int s = 0; s < RB; ++s) {                           // compacted list and right-hand side of the chosen side
+                            const unsigned bit = 1u << rw[s];
+                            const bool on = vrow[s] && (mC32 & bit);
+                            const int rk = __popc(mC32 & (bit - 1u));
+                            list[on ? rk : (C::oD - C::oL) * 2] = rw[s];
+                            yL[on ? rk : C::oD - C::oY] = dual ? rr[s] : z[s];
+                        }
+                        __syncthreads();
+                        const bool mine = i < c;
+                        const int la = mine ? list[i] : 0;
+                        double rhs = mine ? yL[i] : 0.0;
+                        const int tla = PACKED ? la * (la + 1) / 2 : la * LDW;
+                        const ldsd *Mx = dual ? Wp : Pp;
+                        auto midx = [&](int ra, int ta, int lb, int tlb) -> int {
+                            if constexpr (PACKED) return max(ta, tlb) + min(ra, lb);
+                            else return ta + lb;
+                        };
+                        double S[CS];
+                        static_for<CS / 4>([&](auto bgc) {
+                            constexpr int bg = decltype(bgc)::value;
+#pragma unroll
+                            for (int bb = 4 * bg; bb < 4 * bg + 4; ++bb) S[bb] = (bb == i) ? 1.0 : 0.0;
+                            if (4 * bg < cw) {
+                                static_for<4>([&](auto bc) {
+                                    constexpr int bb = 4 * bg + decltype(bc)::value;
+                                    const int lb = rowb_i(la, bb), tlb = PACKED ? rowb_i(tla, bb) : 0;
+                                    const double val = Mx[midx(la, tla, lb, tlb)];
+                                    S[bb] = mine ? val : S[bb];
+                                });
+                            }
+                        });
+                        bool ok = true;
+                        static_for<CS>([&](auto kc) {
+                            constexpr int k = decltype(kc)::value;
+                            if (k < cw) {
+                                isettle<LPI>(S[k]);
+                                const double d = ibcast<LPI>(S[k], k);
+                                ok = ok && (d > 0.0);
+                                const double inv = frcp(d);
+                                const double g = (i == k) ? (inv - 1.0) : -S[k] * inv;
+#pragma unroll
+                                for (int jg = 0; jg < CS / 4; ++jg) {
+                                    if (4 * jg + 3 > k && 4 * jg < cw) {
+                                        if (4 * jg > k) ifmac_self4<LPI>(&S[4 * jg], g, k);
+                                        else {
+#pragma unroll
+                                            for (int j = 4 * jg; j < 4 * jg + 4; ++j)
+                                                if (j > k) ifmac_self<LPI>(S[j], g, k);
+                                        }
+                                    }
+                                }
+                                ifmac_self<LPI>(rhs, g, k);
+                            }
+                        });
+                        const bool rowfail = iballot<LPI>(!ok, q) != 0;
+                        if (mine) xL[la] = rhs;                                  // the solution back to its rows (primal side reads it)
+                        double tt[RB];
+#pragma unroll
+                        for (int s = 0; s < RB; ++s) tt[s] = 0.0;
+                        const int trow[2] = {PACKED ? tri[0] : rw[0] * LDW, RB > 1 ? (PACKED ? tri[RB - 1] : rw[RB - 1] * LDW) : 0};
+                        static_for<CS / 4>([&](auto kgc) {
+                            constexpr int kg = decltype(kgc)::value;
+                            if (4 * kg < cw) {
+                                double wv[4][RB];
+                                static_for<4>([&](auto kc) {
+                                    constexpr int kk = decltype(kc)::value;
+                                    const int lk = rowb_i(la, 4 * kg + kk), tlk = PACKED ? rowb_i(tla, 4 * kg + kk) : 0;
+#pragma unroll
+                                    for (int s = 0; s < RB; ++s) wv[kk][s] = Mx[vrow[s] ? midx(rw[s], trow[s], lk, tlk) : 0];
+                                });
+                                static_for<4>([&](auto kc) {
+                                    constexpr int kk = decltype(kc)::value;
+#pragma unroll
+                                    for (int s = 0; s < RB; ++s) fmac_rowb(tt[s], rhs, wv[kk][s], 4 * kg + kk);
+                                });
+                            }
+                        });
+                        __syncthreads();
+                        // new iterate, gradient on the active rows, tolerances (dual: |lam| in the solution lanes; primal: |g| by row)
+                        double gl[RB];
+                        unsigned ghi = 0u;
+#pragma unroll
+                        for (int s = 0; s < RB; ++s) {
+                            const unsigned bit = 1u << rw[s];
+                            const bool act = vrow[s] && (mA32 & bit);
+                            const double sg = (mL32 & bit) ? -1.0 : 1.0;
+                            const double dl = xL[rw[s]];                         // primal: my row's dlt (rows of F)
+                            const double nv = act ? sg * h[s] : (dual ? vu[s] - tt[s] : vu[s] + dl);
+                            v[s] = busy ? nv : v[s];
+                            gl[s] = (act && !dual) ? tt[s] - z[s] : 0.0;
+                            ghi = max(ghi, (unsigned)__double2hiint(gl[s]) & 0x7fffffffu);
+                        }
+                        const unsigned lhi = (unsigned)__double2hiint(rhs) & 0x7fffffffu;
+                        const double tol = 1e-10 * __hiloint2double((int)row_umax(dual ? (mine ? lhi : 0u) : ghi), 0);
+                        const bool isL = (mL32 >> la) & 1u;
+                        const unsigned keepL = (dual && mine && isL && rhs <= tol) ? (1u << la) : 0u;
+                        const unsigned keepU = (dual && mine && !isL && rhs >= -tol) ? (1u << la) : 0u;
+                        unsigned nL32 = row_or(keepL), nU32 = row_or(keepU);
+                        bool nf = false;
+#pragma unroll
+                        for (int s = 0; s < RB; ++s) {
+                            const unsigned bit = 1u << rw[s];
+                            const bool act = vrow[s] && (mA32 & bit);
+                            const bool fr = vrow[s] && !act;
+                            const bool lo = (fr && v[s] < -h[s] * (1.0 + 1e-12)) || (act && !dual && (mL32 & bit) && gl[s] >= -tol);
+                            const bool up = (fr && v[s] > h[s] * (1.0 + 1e-12)) || (act && !dual && (mU32 & bit) && gl[s] <= tol);
+                            nL32 |= (unsigned)(iballot<LPI>(lo, q) << (LPI * s));
+                            nU32 |= (unsigned)(iballot<LPI>(up, q) << (LPI * s));
+                            nf = nf || (vrow[s] && !(fabs(v[s]) < 1e300));
+                        }
+                        const bool rownf = iballot<LPI>(nf || (mine && !(fabs(rhs) < 1e300)), q) != 0;
+#ifdef LQMPC_R16_PROF
+                        prof_wit += 1; prof_slow += 1; prof_slowt += clock64() - prof_it0;
+#endif
+                        if (busy) {
+                            iters += 1;
+                            if (rowfail || rownf) { failed = true; busy = false; }
+                            else if ((mask_t)nL32 == mL && (mask_t)nU32 == mU) busy = false;
+                            else { mL = nL32; mU = nU32; }
+                        }
+                        __syncthreads();
+                        if (__ballot(busy) == 0ull) break;
+                        continue;
                     }
                 }
                 // publish v_unc, r = v_unc - s h on the active rows (0 elsewhere), the list of the chosen side
