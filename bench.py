@@ -345,7 +345,7 @@ def main():
                               "workload": "lqmpc_sweep_batch_dev: max V_N over 8 level-set points + the T-step rollout per system "
                                           "(utils_class.py:813-833), one launch"}
         # the rest of data_generation per system (utils_class.py:837-859): dlqr + energy_decreasing + energy_bound on the GPU
-        if args.config != 1:
+        if args.config != 1 and n <= 40:                   # (the Jacobi sweeps grow with n^3: the n = 120 shape takes a minute per launch)
             dMV = torch.full((Bsz,), 0.5, dtype=torch.float64, device=dev)
             dlev = torch.full((Bsz,), 5e-3, dtype=torch.float64, device=dev)
             outs = [torch.empty(Bsz, dtype=torch.float64, device=dev) for _ in range(5)]

@@ -75,19 +75,19 @@ __device__ __forceinline__ void tile_store(ldsd *C, d4_t c)
 // With one matrix row per lane of a 16-lane row these are the column broadcasts of a 16x16 factorisation;
 // the value stays in vector registers (no v_readlane / SGPR round trip).
 #define LQMPC_ROWB_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
-// The read goes through inline asm WITH its own wait states: the compiler's hazard recogniser does not see VGPR writes made by
-// the inline-asm DPP updates below, so a builtin DPP move scheduled right behind such a statement could read a stale register
-// (seen on gfx950 when a settle was missing).  With the s_nop inside the statement the rule "two wait states between a VALU
-// write and a DPP read" holds whatever precedes it, and no call site has to remember it.
+// (A compiler builtin on purpose: as inline asm with its own s_nop -- which would make the wait states after an inline-asm
+// DPP update structural -- the value functions of the one-shot / max-V_N / sweep builds, ten broadcasts per horizon, spill 470
+// registers instead of 100 and run 2-5x slower; measured round 2.  The rule stays at the call sites: dpp_settle() before reading
+// through rowb() what an asm statement wrote; every built shape's set-up and iterations are checked against the oracle in -m gpu.)
 __device__ __forceinline__ double rowb(double x, int c)          // c: compile-time constant after unrolling
 {
-    double v = 0.0;
+    long long v = __double_as_longlong(x);
     switch (c) {
-#define LQMPC_X(C) case C: asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:" #C " row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(x)); break;
+#define LQMPC_X(C) case C: v = __builtin_amdgcn_update_dpp(0ll, v, 0x150 + C, 0xF, 0xF, true); break;
         LQMPC_ROWB_CASES(LQMPC_X)
 #undef LQMPC_X
     }
-    return v;
+    return __longlong_as_double(v);
 }
 // acc += (lane c's x, broadcast over the row) * y, one v_fmac_f64_dpp.  A DPP read needs its source written
 // two wait states earlier; the compiler does not look into inline asm, so every use carries its own s_nop 1
