@@ -1074,10 +1074,16 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             for (int a = 0; a < NX; ++a)
 #pragma unroll
                 for (int cc = 0; cc < NX; ++cc) c = __builtin_fma(xs[a] * Qv(a, cc), xs[cc], c);
-            static_for<N>([&](auto kc) {
-                constexpr int st = decltype(kc)::value;
+            // the optimal inputs by row through LDS, then a ROLLED loop over the stages (unrolled with one DPP broadcast per input
+            // the ten stages of C3 kept ~100 registers in scratch in the one-shot / max-V_N / sweep builds)
+#pragma unroll
+            for (int s = 0; s < RB; ++s) xL[rw[s]] = vrow[s] ? fmin(fmax(v[s], -h[s]), h[s]) + ctr[s] : 0.0;
+            __syncthreads();
+#pragma unroll 1
+            for (int st = 0; st < N; ++st) {
                 double u[NU], xn[NX];
-                stage_input(v, st, u);
+#pragma unroll
+                for (int k = 0; k < NU; ++k) u[k] = xL[st * NU + k];
 #pragma unroll
                 for (int a = 0; a < NX; ++a) {
                     double acc = 0.0;
@@ -1101,7 +1107,8 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 for (int k = 0; k < NU; ++k)
 #pragma unroll
                     for (int j = 0; j < NU; ++j) c = __builtin_fma(u[k] * Rv(k, j), u[j], c);
-            });
+            }
+            __syncthreads();
             return c;
         };
         if (MODE == MODE_SOLVE) {
