@@ -78,7 +78,7 @@ __device__ __forceinline__ void tile_store(ldsd *C, d4_t c)
 // (A compiler builtin on purpose: as inline asm with its own s_nop -- which would make the wait states after an inline-asm
 // DPP update structural -- the value functions of the one-shot / max-V_N / sweep builds, ten broadcasts per horizon, spill 470
 // registers instead of 100 and run 2-5x slower; measured round 2.  The rule stays at the call sites: dpp_settle() before reading
-// through rowb() what an asm statement wrote; every built shape's set-up and iterations are checked against the oracle in -m gpu.)
+// through rowb() what an asm statement wrote; every built shape's set-up and iterations are checked in the -m gpu parity tests.)
 __device__ __forceinline__ double rowb(double x, int c)          // c: compile-time constant after unrolling
 {
     long long v = __double_as_longlong(x);
