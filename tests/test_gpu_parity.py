@@ -499,3 +499,26 @@ def test_sweep_hand_back_merges_status_and_iters(solver):
         assert np.array_equal(g["iters"], m["iters"] + r["iters"])
     finally:
         solver.set_options(r16_maxit=12, max_iter=50, polish=1)
+
+
+def test_c4_eight_way_sharded_form_equals_the_single_batch(solver, golden_dir):
+    """BASELINE config 4 is 262 144 systems cut over 8 GPUs (32 768 per rank, lq_mpc_amd.dist.shard_batch).  The eight shards,
+    rolled out one after the other on the one GPU here, must give the single-batch result bit for bit (no result depends on
+    which instances share a launch or on their position in the difficulty order) -- the property the 8-GPU run relies on."""
+    from lq_mpc_amd import dist as ld
+    b = synth.make_batch(4, fixture_dir=golden_dir)
+    assert b["Bsz"] == 262144
+    full = solver.rollout_batch(30, *args(b), b["x0"], b["A_true"], b["B_true"])
+    assert np.all(full["status"] == 0)
+    parts = []
+    for r in range(8):
+        sh = ld.shard_batch(b, r, 8)
+        assert sh["A"].shape[-1] == 32768 and sh["shard"] == (r * 32768, (r + 1) * 32768)
+        g = solver.rollout_batch(30, *args(sh), sh["x0"], sh["A_true"], sh["B_true"])
+        assert "r64" in solver.last_kernel() and np.all(g["status"] == 0)
+        parts.append(g["J_T"])
+    assert np.array_equal(np.concatenate(parts), full["J_T"])
+    idx = np.random.default_rng(3).choice(b["Bsz"], 256, replace=False)
+    sub = dict(b, A=np.ascontiguousarray(b["A"][:, :, idx]), B=np.ascontiguousarray(b["B"][:, :, idx]))
+    ref = orc.rollout_batch(30, *args(sub), np.ascontiguousarray(b["x0"][:, idx]), b["A_true"], b["B_true"])
+    assert rel(full["J_T"][idx], ref["J_T"]) < TIGHT
