@@ -2,7 +2,9 @@
 batch and on the same models with x0 scaled to 1e-3 (no constrained step at all: set-up + T iteration-free steps)."""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
-from lq_mpc_amd import BatchSolver, synth
+import os
+from lq_mpc_amd import BatchSolver, synth, _lib
+if os.environ.get('LQMPC_LIB'): _lib.LIB_PATH = os.path.abspath(os.environ['LQMPC_LIB'])
 dev = torch.device('cuda', 0)
 s = BatchSolver(0, stream=torch.cuda.current_stream(dev).cuda_stream)
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
