@@ -256,7 +256,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         static_assert(NX * NX <= LPI, "one lane per element of a power of A");
         auto gA = [&](int a, int c) -> double { return p.rec ? p.rec[b * REC + a * NX + c] : p.A[(long long)(a * NX + c) * Bsz + b]; };
         auto gB = [&](int a, int k) -> double { return p.rec ? p.rec[b * REC + NX * NX + a * NU + k] : p.B[(long long)(a * NU + k) * Bsz + b]; };
-        double ma[RB][NX];
+        double ma[RB][NX], bcol[RB][NX];         // my rows' columns of A^a B, and of B itself
         {   // the powers of A, one element per lane: A^(m+1)(ea, ek) = A(ea, :) . A^m(:, ek), through the table itself
             const bool el = i < NX * NX;
             const int ea = el ? i / NX : 0, ek = el ? i % NX : 0;
@@ -280,7 +280,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 const int base = (mm > 0 ? mm - 1 : 0) * NX * NX;
                 double bk[NX];
 #pragma unroll
-                for (int a = 0; a < NX; ++a) bk[a] = gB(a, uk);
+                for (int a = 0; a < NX; ++a) { bk[a] = gB(a, uk); bcol[s][a] = bk[a]; }
 #pragma unroll
                 for (int a = 0; a < NX; ++a) {
                     double t = 0.0;
@@ -291,65 +291,78 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             }
         }
         RPROF(0);
-        double pm[RB][NX];
+        // Condensing through the Lyapunov-type recursion (round 2; it replaced the products T(i,j) = m_i'P_T m_j + ..., their sums along
+        // the stage diagonals and a horizon-long loop for the Fq rows).  With Lt_k = sum_{r >= k} (A')^(r-k) Q_r A^(r-k), i.e.
+        //   Lt_N = P_T,   Lt_k = Q + A' Lt_{k+1} A      (N - 1 stage updates of an NX x NX matrix, one element per lane),
+        // and y_i = Lt_{bi+1} b_ui for row i = (stage bi, input ui):
+        //   H(i, j) = y_i . m_(bi-bj),uj = y_i . MA[j + a_i NU]   (j <= i: ONE NX-term dot product per entry of the triangle),
+        //   Fq(i, :) = 2 y_i' A^(bi+1)                             (one NX x NX product per row),
+        // because Gamma'Qbar Gamma's block (bi, bj) is B' Lt_{bi+1} A^(bi-bj) B and Gamma'Qbar Phi's block row bi is B' Lt_{bi+1} A^(bi+1).
+        static_assert(2 * NU >= NX, "the table of the Lt_k takes the place of two row-image tables");
+        constexpr int NN = NX * NX;
+        ldsd *LT = PM;                                   // Lt_k at LT[(k-1) NN ..], k = 1..N
+        {
+            const bool el = i < NN;
+            const int ea = el ? i / NX : 0, ek = el ? i % NX : 0;
+            const double qe = el ? sh[p.so.Q + ea * NX + ek] : 0.0;
+            if (el) LT[(N - 1) * NN + i] = sh[p.so.P + ea * NX + ek];
+            __syncthreads();
+#pragma unroll 1
+            for (int k = N - 1; k >= 1; --k) {
+                double t1 = 0.0;                         // (Lt_{k+1} A)(ea, ek); A = AP[0]
 #pragma unroll
-        for (int s = 0; s < RB; ++s) {
-            double qmv[NX];
+                for (int l = 0; l < NX; ++l) t1 = __builtin_fma(LT[k * NN + ea * NX + l], AP[l * NX + ek], t1);
+                if (el) Pp[i] = t1;                      // (the P region is free until the rows of P are written below)
+                __syncthreads();
+                double t2 = qe;                          // Q + (A' (Lt_{k+1} A))(ea, ek)
 #pragma unroll
-            for (int a = 0; a < NX; ++a) {
-                double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-                for (int c = 0; c < NX; ++c) {
-                    t1 = __builtin_fma(sh[p.so.P + a * NX + c], ma[s][c], t1);
-                    t2 = __builtin_fma(sh[p.so.Q + a * NX + c], ma[s][c], t2);
-                }
-                pm[s][a] = t1; qmv[a] = t2;
-            }
-            if (vrow[s]) {
-#pragma unroll
-                for (int a = 0; a < NX; ++a) { MA[rw[s] * NX + a] = ma[s][a]; PM[rw[s] * NX + a] = pm[s][a]; QM[rw[s] * NX + a] = qmv[a]; }
+                for (int l = 0; l < NX; ++l) t2 = __builtin_fma(AP[l * NX + ea], Pp[l * NX + ek], t2);
+                if (el) LT[(k - 1) * NN + i] = t2;
+                __syncthreads();
             }
         }
-        __syncthreads();
-        // T(i, j), j <= i, into the P region: a row slot computes its own diagonal block and, transposed, the blocks below it
 #pragma unroll
         for (int s = 0; s < RB; ++s) {
-            const bool nxt = vrow[s] && rw[s] + NU < n;
-            double man[NX];
+            if (vrow[s]) {
 #pragma unroll
-            for (int a = 0; a < NX; ++a) man[a] = nxt ? MA[(rw[s] + NU) * NX + a] : 0.0;
-#pragma unroll
-            for (int j = 0; j < n; ++j) {
-                if (j < LPI * s) continue;                             // static: the slot of row j computes these, transposed (T is symmetric)
-                double t = 0.0;
-#pragma unroll
-                for (int a = 0; a < NX; ++a) t = __builtin_fma(ma[s][a], PM[j * NX + a], t);
-                if (j + NU < n) {
-#pragma unroll
-                    for (int a = 0; a < NX; ++a) t = __builtin_fma(man[a], QM[(j + NU) * NX + a] - PM[(j + NU) * NX + a], t);
-                }
-                if (j < LPI * s + LPI) Pp[(vrow[s] && j <= rw[s]) ? ad(rw[s], tri[s], j) : DUMMY] = t;
-                else Pp[vrow[s] ? (PACKED ? j * (j + 1) / 2 + rw[s] : j * LDW + rw[s]) : DUMMY] = t;   // (j, my row): a later slot's row
-                if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // straight-line code: keep the loads near their use
+                for (int a = 0; a < NX; ++a) MA[rw[s] * NX + a] = ma[s][a];
             }
         }
         __syncthreads();
         RPROF(1);
-        // H = suffix sums of T along the stage diagonals, in place: a lane walks whole diagonals from their far end
-        // (chain c starts at (i0, j0) = (c / NU, c % NU), j0 <= i0, and steps by (NU, NU)); P = 2 (H + Rbar)
-#pragma unroll 1
-        for (int c = i; c < n * NU; c += LPI) {
-            const int i0 = c / NU, j0 = c % NU;
-            if (j0 <= i0) {
-                const double radd = (i0 < NU) ? sh[p.so.R + i0 * NU + j0] : 0.0;
-                double acc = 0.0;
-#pragma unroll 1
-                for (int s2 = (n - 1 - i0) / NU; s2 >= 0; --s2) {
-                    const int r = i0 + s2 * NU, cc = j0 + s2 * NU;
-                    const int idx = PACKED ? r * (r + 1) / 2 + cc : r * LDW + cc;
-                    acc += Pp[idx];
-                    Pp[idx] = 2.0 * (acc + radd);
-                }
+        double Facc[RB][NX];
+#pragma unroll
+        for (int s = 0; s < RB; ++s) {
+            const int bi = vrow[s] ? rw[s] / NU : 0, ui = rw[s] % NU;
+            double yv[NX], rrow[NU];
+#pragma unroll
+            for (int x = 0; x < NX; ++x) {
+                double t = 0.0;
+#pragma unroll
+                for (int l = 0; l < NX; ++l) t = __builtin_fma(LT[bi * NN + x * NX + l], bcol[s][l], t);
+                yv[x] = vrow[s] ? t : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < NU; ++k) rrow[k] = sh[p.so.R + ui * NU + k];
+            // my row of P = 2 (H + Rbar), columns j <= i
+            const ldsd *MAi = MA + (N - 1 - bi) * NU * NX;
+#pragma unroll
+            for (int j = 0; j < n; ++j) {
+                if (j >= LPI * (s + 1)) continue;                      // static: beyond the last row of this slot
+                double t = 0.0;
+#pragma unroll
+                for (int x = 0; x < NX; ++x) t = __builtin_fma(yv[x], MAi[j * NX + x], t);
+                const double radd = (j / NU == bi) ? rrow[j % NU] : 0.0;
+                Pp[(vrow[s] && j <= rw[s]) ? ad(rw[s], tri[s], j) : DUMMY] = 2.0 * (t + radd);
+                if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // straight-line code: keep the loads near their use
+            }
+            // my row of Fq
+#pragma unroll
+            for (int c = 0; c < NX; ++c) {
+                double t = 0.0;
+#pragma unroll
+                for (int x = 0; x < NX; ++x) t = __builtin_fma(yv[x], AP[bi * NN + x * NX + c], t);
+                Facc[s][c] = vrow[s] ? 2.0 * t : 0.0;
             }
         }
         __syncthreads();
@@ -371,40 +384,6 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 if (!PACKED) Pp[(vrow[s] && j > rw[s]) ? rw[s] * LDW + j : DUMMY] = Wr[s][j];   // the upper triangle: rows are stored in full
         RPROF(2);
         __builtin_amdgcn_sched_barrier(0);
-        // Fq rows: power by power (d outer), so that each A^(N-d) is fetched once for both row slots
-        double Facc[RB][NX];
-#pragma unroll
-        for (int s = 0; s < RB; ++s)
-#pragma unroll
-            for (int c = 0; c < NX; ++c) Facc[s][c] = 0.0;
-#pragma unroll UNR_FQ
-        for (int d = 0; d < N; ++d) {
-            double Apw[NX][NX];
-#pragma unroll
-            for (int a = 0; a < NX; ++a)
-#pragma unroll
-                for (int c = 0; c < NX; ++c) Apw[a][c] = AP[(N - 1 - d) * NX * NX + a * NX + c];
-#pragma unroll
-            for (int s = 0; s < RB; ++s) {
-                if (LPI * s + d * NU >= n) continue;              // uniform: beyond the last row for every row of this slot
-                const bool in = vrow[s] && rw[s] + d * NU < n;
-                double wmv[NX];
-#pragma unroll
-                for (int a = 0; a < NX; ++a) wmv[a] = (d == 0) ? pm[s][a] : (in ? QM[(rw[s] + d * NU) * NX + a] : 0.0);
-#pragma unroll
-                for (int c = 0; c < NX; ++c) {
-                    double t = Facc[s][c];
-#pragma unroll
-                    for (int a = 0; a < NX; ++a) t = __builtin_fma(wmv[a], Apw[a][c], t);
-                    Facc[s][c] = t;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int s = 0; s < RB; ++s)
-#pragma unroll
-            for (int c = 0; c < NX; ++c) Facc[s][c] = vrow[s] ? 2.0 * Facc[s][c] : 0.0;
         RPROF(3);
         // constant part of the linear term: qr = 2 gref + P centre (references / off-centre boxes only)
         bool has_lin = p.has_ref != 0;
