@@ -263,14 +263,28 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             double Ar[NX];
 #pragma unroll
             for (int c = 0; c < NX; ++c) Ar[c] = gA(ea, c);
-            if (el) AP[i] = gA(ea, ek);
+            // ... and, riding on the same stages, the recursion Lt_N = P_T, Lt_k = Q + A' Lt_{k+1} A of the condensing below (stage m
+            // makes A^(m+1) and Lt_(N-m); the two chains are independent, so the second costs one more barrier per stage, not N more)
+            constexpr int NN_ = NX * NX;
+            ldsd *LT_ = PM;
+            const double qe = el ? sh[p.so.Q + ea * NX + ek] : 0.0;
+            if (el) { AP[i] = gA(ea, ek); LT_[(N - 1) * NN_ + i] = sh[p.so.P + ea * NX + ek]; }
 #pragma unroll 1
             for (int m = 1; m < N; ++m) {
+                const int k = N - m;
                 __syncthreads();
-                double t = 0.0;
+                double t = 0.0, t1 = 0.0;
 #pragma unroll
-                for (int c = 0; c < NX; ++c) t = __builtin_fma(Ar[c], AP[(m - 1) * NX * NX + c * NX + ek], t);
-                if (el) AP[m * NX * NX + i] = t;
+                for (int c = 0; c < NX; ++c) {
+                    t = __builtin_fma(Ar[c], AP[(m - 1) * NN_ + c * NX + ek], t);
+                    t1 = __builtin_fma(LT_[k * NN_ + ea * NX + c], AP[c * NX + ek], t1);      // (Lt_{k+1} A)(ea, ek)
+                }
+                if (el) { AP[m * NN_ + i] = t; Pp[i] = t1; }       // (the P region is free until the rows of P are written below)
+                __syncthreads();
+                double t2 = qe;                                      // Q + (A' (Lt_{k+1} A))(ea, ek)
+#pragma unroll
+                for (int c = 0; c < NX; ++c) t2 = __builtin_fma(AP[c * NX + ea], Pp[c * NX + ek], t2);
+                if (el) LT_[(k - 1) * NN_ + i] = t2;
             }
             __syncthreads();
             // my rows' columns of M_a = A^a B
@@ -301,26 +315,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         static_assert(2 * NU >= NX, "the table of the Lt_k takes the place of two row-image tables");
         constexpr int NN = NX * NX;
         ldsd *LT = PM;                                   // Lt_k at LT[(k-1) NN ..], k = 1..N
-        {
-            const bool el = i < NN;
-            const int ea = el ? i / NX : 0, ek = el ? i % NX : 0;
-            const double qe = el ? sh[p.so.Q + ea * NX + ek] : 0.0;
-            if (el) LT[(N - 1) * NN + i] = sh[p.so.P + ea * NX + ek];
-            __syncthreads();
-#pragma unroll 1
-            for (int k = N - 1; k >= 1; --k) {
-                double t1 = 0.0;                         // (Lt_{k+1} A)(ea, ek); A = AP[0]
-#pragma unroll
-                for (int l = 0; l < NX; ++l) t1 = __builtin_fma(LT[k * NN + ea * NX + l], AP[l * NX + ek], t1);
-                if (el) Pp[i] = t1;                      // (the P region is free until the rows of P are written below)
-                __syncthreads();
-                double t2 = qe;                          // Q + (A' (Lt_{k+1} A))(ea, ek)
-#pragma unroll
-                for (int l = 0; l < NX; ++l) t2 = __builtin_fma(AP[l * NX + ea], Pp[l * NX + ek], t2);
-                if (el) LT[(k - 1) * NN + i] = t2;
-                __syncthreads();
-            }
-        }
+        // (the recursion itself ran with the powers of A above)
 #pragma unroll
         for (int s = 0; s < RB; ++s) {
             if (vrow[s]) {
