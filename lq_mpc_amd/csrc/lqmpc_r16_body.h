@@ -852,6 +852,112 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                         if (__ballot(busy) == 0ull) break;
                         continue;
                     }
+                } else if (!any_primal) {
+                    // ---- one instance per wavefront, dual side: the same skeleton with the broadcasts as v_readlane -- everything about
+                    // the instance is wave-uniform, so the column indices, the multipliers and the new masks live in scalar registers ----
+                    {
+                        const mask_t bit = 1ull << rw[0];
+                        const bool on = vrow[0] && (mC & bit);
+                        const int rk = __popcll(mC & (bit - 1ull));
+                        const double sg = (mL & bit) ? -1.0 : 1.0;
+                        list[on ? rk : (C::oD - C::oL) * 2] = rw[0];
+                        rL[on ? rk : C::oD - C::oR] = __builtin_fma(-sg, h[0], vu[0]);
+                    }
+                    __syncthreads();
+                    const bool mine = i < c;
+                    const int la = mine ? list[i] : 0;
+                    double rhs = mine ? rL[i] : 0.0;
+                    const int tla = PACKED ? la * (la + 1) / 2 : la * LDW;
+                    auto widx = [&](int ra, int ta, int lb, int tlb) -> int {
+                        if constexpr (PACKED) return max(ta, tlb) + min(ra, lb);
+                        else return ta + lb;
+                    };
+                    double S[CS];
+                    static_for<CS / 4>([&](auto bgc) {
+                        constexpr int bg = decltype(bgc)::value;
+#pragma unroll
+                        for (int bb = 4 * bg; bb < 4 * bg + 4; ++bb) S[bb] = (bb == i) ? 1.0 : 0.0;
+                        if (4 * bg < cw) {
+                            static_for<4>([&](auto bc) {
+                                constexpr int bb = 4 * bg + decltype(bc)::value;
+                                const int lb = __builtin_amdgcn_readlane(la, bb), tlb = PACKED ? __builtin_amdgcn_readlane(tla, bb) : 0;
+                                const double val = Wp[widx(la, tla, lb, tlb)];
+                                S[bb] = mine ? val : S[bb];
+                            });
+                        }
+                    });
+                    bool ok = true;
+                    static_for<CS>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        if (k < cw) {
+                            const double d = ibcast<LPI>(S[k], k);
+                            ok = ok && (d > 0.0);
+                            const double inv = frcp(d);
+                            const double g = (i == k) ? (inv - 1.0) : -S[k] * inv;
+#pragma unroll
+                            for (int jg = 0; jg < CS / 4; ++jg) {
+                                if (4 * jg + 3 > k && 4 * jg < cw) {
+                                    if (4 * jg > k) ifmac_self4<LPI>(&S[4 * jg], g, k);
+                                    else {
+#pragma unroll
+                                        for (int j = 4 * jg; j < 4 * jg + 4; ++j)
+                                            if (j > k) ifmac_self<LPI>(S[j], g, k);
+                                    }
+                                }
+                            }
+                            ifmac_self<LPI>(rhs, g, k);
+                        }
+                    });
+                    const bool rowfail = iballot<LPI>(!ok, q) != 0;
+                    // t = W_FA lam on my row; the largest multiplier and the bounds that stay, in scalar registers
+                    double tt = 0.0;
+                    const int trow0 = PACKED ? tri[0] : rw[0] * LDW;
+                    unsigned smax = 0u;
+                    const unsigned lhi = (unsigned)__double2hiint(rhs) & 0x7fffffffu;
+                    static_for<CS>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        if (k < cw) {
+                            const int lk = __builtin_amdgcn_readlane(la, k), tlk = PACKED ? __builtin_amdgcn_readlane(tla, k) : 0;
+                            const double wv = Wp[vrow[0] ? widx(rw[0], trow0, lk, tlk) : 0];
+                            tt = __builtin_fma(wg::rdlane(rhs, k), wv, tt);
+                            smax = max(smax, (unsigned)__builtin_amdgcn_readlane((int)lhi, k));
+                        }
+                    });
+                    const double tol = 1e-10 * __hiloint2double((int)smax, 0);
+                    const bool isL = (mL >> la) & 1ull;
+                    const mask_t kL = __ballot(mine && isL && rhs <= tol), kU = __ballot(mine && !isL && rhs >= -tol);   // by unknown k
+                    mask_t nL = 0, nU = 0;
+                    static_for<CS>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        if (k < cw) {
+                            const int lk = __builtin_amdgcn_readlane(la, k);
+                            nL |= ((kL >> k) & 1ull) << lk;
+                            nU |= ((kU >> k) & 1ull) << lk;
+                        }
+                    });
+                    {
+                        const mask_t bit = 1ull << rw[0];
+                        const bool act = vrow[0] && (mA & bit);
+                        const double sg = (mL & bit) ? -1.0 : 1.0;
+                        const double nv = act ? sg * h[0] : vu[0] - tt;
+                        v[0] = busy ? nv : v[0];
+                        const bool fr = vrow[0] && !act;
+                        nL |= __ballot(fr && v[0] < -h[0] * (1.0 + 1e-12));
+                        nU |= __ballot(fr && v[0] > h[0] * (1.0 + 1e-12));
+                    }
+                    const bool rownf = __ballot((vrow[0] && !(fabs(v[0]) < 1e300)) || (mine && !(fabs(rhs) < 1e300))) != 0ull;
+#ifdef LQMPC_R16_PROF
+                    prof_wit += 1; prof_fast += 1; prof_ph[7] += clock64() - prof_it0;
+#endif
+                    if (busy) {
+                        iters += 1;
+                        if (rowfail || rownf) { failed = true; busy = false; }
+                        else if (nL == mL && nU == mU) busy = false;
+                        else { mL = nL; mU = nU; }
+                    }
+                    __syncthreads();
+                    if (__ballot(busy) == 0ull) break;
+                    continue;
                 }
                 // publish v_unc, r = v_unc - s h on the active rows (0 elsewhere), the list of the chosen side
 #pragma unroll
