@@ -364,7 +364,7 @@ def main():
             extra["bounds"] = {"value": round(Bsz / (msb * 1e-3), 1), "unit": "systems/s", "kernel_ms_per_launch": round(msb, 4),
                                "dlqr_not_converged": int((dstb == 1).sum().item()) + int((dstb == 2).sum().item()),
                                "workload": "lqmpc_bounds_batch_dev: dlqr (doubling) + local radius + stability numbers + alpha/beta/xi/eta/bound "
-                                           "per system (utils_class.py:837-859), one instance per lane, Jacobi sweeps on N n_u x N n_u matrices"}
+                                           "per system (utils_class.py:837-859), one instance per lane; Householder tridiagonalisation + bisection for the two N n_u x N n_u eigenproblems"}
         # single-call latency: the reference's call shape is ONE instance per solve() (utils_class.py:269)
         lat = {}
         for m in (1, 64, 4096):

@@ -6,7 +6,7 @@ namespace lqmpc {
 
 // workspace offsets (doubles per instance): the doubling iterates and their temporaries, the gain, M_d = A^d B, one N n_u x N n_u matrix
 struct BoundsOff {
-    int Ak, Gk, Hk, T1, T2, T3, T4, K, U1, U2, Md, E, total;
+    int Ak, Gk, Hk, T1, T2, T3, T4, K, U1, U2, Md, E, V, total;
 };
 BoundsOff bounds_offsets(int nx, int nu, int N);
 

@@ -12,8 +12,8 @@
 //   L_V, N_0 = ex_stability_bounds                    utils.py:567-584
 //   omega_{N,1}, omega_{N,0.5}, eta, h, xi            utils.py:393-409, 469-538; utils_class.py:344-373
 //   alpha, beta = energy_bound                        utils_class.py:308-342; utils.py:78-117, 186-334
-//              |Gamma|_2, |Phi|_2, |A|_2, |B|_2, |K|_2 and lambda_min(hat H) from cyclic Jacobi sweeps on the Gram matrices
-//              (Gamma' Gamma, hat H are N n_u x N n_u); bar_u, bar_d_u in closed form for a box (utils.py:592-650 uses Gurobi)
+//              |Phi|_2, |A|_2, |B|_2, |K|_2 from cyclic Jacobi sweeps on the small Gram matrices; |Gamma|_2 and lambda_min(hat H)
+//              (Gamma' Gamma, hat H are N n_u x N n_u) from a Householder tridiagonalisation and bisection on the Sturm count; bar_u, bar_d_u in closed form for a box (utils.py:592-650 uses Gurobi)
 //   bound    = (alpha V_expert + beta) / (1 - xi - eta)                                    utils_class.py:858-859
 // Two quirks of the reference are kept because its golden data contain them (the constant 1.21 and the "+0.4" of
 // utils.py:358, 364) and so is the Kronecker ordering of hat H (utils.py:316-319, np.kron(R, I_N) + Gamma' np.kron(Q, I_{N+1}) Gamma);
@@ -40,6 +40,7 @@ BoundsOff bounds_offsets(int nx, int nu, int N)
     o.U2 = c; c += nu * nx;
     o.Md = c; c += N * nx * nu;
     o.E = c;  c += n * n;
+    o.V = c;  c += 4 * n;
     o.total = c;
     return o;
 }
@@ -130,6 +131,77 @@ __device__ void sym_eig_extremes(const Lane &w, int M, int n, double &emax, doub
         const double d = w(M, p * n + p);
         emax = fmax(emax, d); emin = fmin(emin, d);
     }
+}
+
+// extreme eigenvalues of the symmetric n x n matrix at M (destroyed) for the large matrices (Gamma'Gamma, hat H): Householder
+// tridiagonalisation (~5 n^3 / 3 workspace accesses, against ~16 n^3 per Jacobi sweep and 6-10 sweeps) and bisection on the Sturm
+// count of the tridiagonal matrix (d, e).  V: 4 n entries of scratch (v | p / w | d | e).
+__device__ void sym_eig_extremes_tridiag(const Lane &w, int M, int n, int V, double &emax, double &emin)
+{
+    const int v = V, pw = V + n, d = V + 2 * n, e = V + 3 * n;
+    if (n == 1) { emax = emin = w(M, 0); return; }
+    for (int k = 0; k + 2 < n; ++k) {
+        const int m = n - k - 1;                                     // order of the trailing block A22 = M[k+1.., k+1..]
+        double nrm2 = 0.0;
+        for (int r = 0; r < m; ++r) { const double x = w(M, (k + 1 + r) * n + k); nrm2 = __builtin_fma(x, x, nrm2); }
+        const double x0 = w(M, (k + 1) * n + k);
+        w(d, k) = w(M, k * n + k);
+        const double tail2 = nrm2 - x0 * x0;
+        if (!(tail2 > 0.0)) { w(e, k) = x0; continue; }              // nothing below the subdiagonal in this column
+        const double alpha = (x0 > 0.0) ? -sqrt(nrm2) : sqrt(nrm2);
+        const double r2 = 0.5 * (nrm2 - x0 * alpha), rinv = 1.0 / (2.0 * sqrt(r2));      // H = I - 2 v v',  |v| = 1
+        for (int r = 0; r < m; ++r) w(v, r) = (w(M, (k + 1 + r) * n + k) - (r == 0 ? alpha : 0.0)) * rinv;
+        w(e, k) = alpha;
+        double K = 0.0;                                              // p = A22 v,  K = v'p
+        for (int r = 0; r < m; ++r) {
+            double acc = 0.0;
+            for (int c = 0; c < m; ++c) acc = __builtin_fma(w(M, (k + 1 + r) * n + (k + 1 + c)), w(v, c), acc);
+            w(pw, r) = acc;
+            K = __builtin_fma(w(v, r), acc, K);
+        }
+        for (int r = 0; r < m; ++r) w(pw, r) = __builtin_fma(-K, w(v, r), w(pw, r));      // w = p - K v
+        for (int r = 0; r < m; ++r) {                                // A22 -= 2 (v w' + w v')
+            const double vr2 = 2.0 * w(v, r), wr2 = 2.0 * w(pw, r);
+            for (int c = 0; c < m; ++c) {
+                const int idx = (k + 1 + r) * n + (k + 1 + c);
+                w(M, idx) = w(M, idx) - vr2 * w(pw, c) - wr2 * w(v, c);
+            }
+        }
+    }
+    w(d, n - 2) = w(M, (n - 2) * n + (n - 2));
+    w(e, n - 2) = w(M, (n - 1) * n + (n - 2));
+    w(d, n - 1) = w(M, (n - 1) * n + (n - 1));
+    double lo = 1e308, hi = -1e308;                                  // Gershgorin
+    for (int i = 0; i < n; ++i) {
+        const double rad = (i > 0 ? fabs(w(e, i - 1)) : 0.0) + (i + 1 < n ? fabs(w(e, i)) : 0.0);
+        lo = fmin(lo, w(d, i) - rad); hi = fmax(hi, w(d, i) + rad);
+    }
+    const double span = fmax(hi - lo, 1e-300), tiny = 1e-300 + 2.3e-16 * fmax(fabs(lo), fabs(hi));
+    auto count_below = [&](double x) {                               // number of eigenvalues < x
+        int cnt = 0;
+        double q = w(d, 0) - x;
+        if (q < 0.0) ++cnt;
+        for (int i = 1; i < n; ++i) {
+            if (fabs(q) < tiny) q = (q < 0.0) ? -tiny : tiny;
+            const double ei = w(e, i - 1);
+            q = w(d, i) - x - ei * ei / q;
+            if (q < 0.0) ++cnt;
+        }
+        return cnt;
+    };
+    lo -= 1e-3 * span; hi += 1e-3 * span;
+    double a = lo, b = hi;                                           // smallest: count(a) = 0, count(b) >= 1
+    for (int it = 0; it < 120 && b - a > 4.5e-16 * fmax(fabs(a), fabs(b)); ++it) {
+        const double mid = 0.5 * (a + b);
+        if (count_below(mid) >= 1) b = mid; else a = mid;
+    }
+    emin = 0.5 * (a + b);
+    a = lo; b = hi;                                                  // largest: count(a) <= n - 1, count(b) = n
+    for (int it = 0; it < 120 && b - a > 4.5e-16 * fmax(fabs(a), fabs(b)); ++it) {
+        const double mid = 0.5 * (a + b);
+        if (count_below(mid) >= n) b = mid; else a = mid;
+    }
+    emax = 0.5 * (a + b);
 }
 
 // spectral norm of the m x k matrix at A (row-major) through the smaller Gram matrix, built at E (needs min(m,k)^2 entries)
@@ -329,7 +401,7 @@ __global__ void __launch_bounds__(64) lqmpc_bounds_kernel(BoundsParams p)
                     t = __builtin_fma(w(o.Md, ((r - 1 - c1) * nx + a) * nu + k1), w(o.Md, ((r - 1 - c2) * nx + a) * nu + k2), t);
             w(o.E, i * n + j) = t; w(o.E, j * n + i) = t;
         }
-    sym_eig_extremes(w, o.E, n, emax, emin);
+    sym_eig_extremes_tridiag(w, o.E, n, o.V, emax, emin);
     const double nG = sqrt(fmax(emax, 0.0));
     // hat H = kron(R, I_N) + Gamma' kron(Q, I_{N+1}) Gamma with the index pairing of utils.py:316-319
     const int rows = (N + 1) * nx;
@@ -351,7 +423,7 @@ __global__ void __launch_bounds__(64) lqmpc_bounds_kernel(BoundsParams p)
         }
     for (int i = 0; i < n; ++i)                                        // the product above is symmetric when Q is; mirror the lower triangle
         for (int j = 0; j < i; ++j) w(o.E, j * n + i) = w(o.E, i * n + j);
-    sym_eig_extremes(w, o.E, n, emax, emin);
+    sym_eig_extremes_tridiag(w, o.E, n, o.V, emax, emin);
     const double min_H = emin;
 
     // ---------------- energy_decreasing: xi, eta (utils_class.py:344-373) ----------------
