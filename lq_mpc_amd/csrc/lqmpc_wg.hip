@@ -816,22 +816,21 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
             // NaN) leaves everything as it was and takes the general path below.
             ldsd *uw = lds + w.o.vw;
             ldsd *cur = xs, *nxt = xs + nx;                           // the state ping-pongs between the two halves: one barrier per step
-            // (NXC, NUC) > 0: the dimensions at compile time -- my row of G, of the plant and of the weights stay in registers over the
+            // (NXC, NUC) > 0: the dimensions at compile time (C5's) -- my row of G and of the plant stay in registers over the
             // steps and only the state and the inputs go through LDS; (0, 0): run-time dimensions, everything read from LDS per step
             auto interior = [&](auto nxc, auto nuc) {
                 constexpr int NXC = decltype(nxc)::value, NUC = decltype(nuc)::value;
                 constexpr bool FIX = NXC > 0;
-                double g[FIX ? NXC : 1], ar[FIX ? NXC : 1], br[FIX ? NUC : 1], qw[FIX ? NXC : 1], rw_[FIX ? NUC : 1];
+                double g[FIX ? NXC : 1], ar[FIX ? NXC : 1], br[FIX ? NUC : 1];    // (the weights' rows stay in LDS: they are off the chain)
                 if constexpr (FIX) {
-                    const int tx = t < NXC ? t : 0, tu = t < NUC ? t : 0;
+                    const int tx = t < NXC ? t : 0;
 #pragma unroll
                     for (int a = 0; a < NXC; ++a) {
                         g[a] = w.own ? lds[w.o.G + a * w.np + t] : 0.0;
                         ar[a] = sh[p.so.At + tx * NXC + a];
-                        qw[a] = sh[p.so.Q + tx * NXC + a];
                     }
 #pragma unroll
-                    for (int k = 0; k < NUC; ++k) { br[k] = sh[p.so.Bt + tx * NUC + k]; rw_[k] = sh[p.so.R + tu * NUC + k]; }
+                    for (int k = 0; k < NUC; ++k) br[k] = sh[p.so.Bt + tx * NUC + k];
                 }
                 for (;;) {
                     double vu, xn = 0.0;
@@ -863,22 +862,12 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
                     if (__syncthreads_or(out ? 1 : 0)) break;
                     // inside the box: commit the step (costs, trajectories); the next round writes the half nobody reads any more
                     if (t < nx) {
-                        double qx = 0.0;
-                        if constexpr (FIX) {
-#pragma unroll
-                            for (int a = 0; a < NXC; ++a) qx = __builtin_fma(qw[a], nxt[a], qx);
-                        } else qx = ldot(sh + p.so.Q + t * nx, 1, nxt, 1, nx);
-                        cost = __builtin_fma(xn, qx, cost);
+                        cost = __builtin_fma(xn, ldot(sh + p.so.Q + t * nx, 1, nxt, 1, nx), cost);
                         if (p.X) p.X[((long long)t * (p.T + 1) + step + 1) * Bsz + b] = xn;
                     }
                     if (t < nu) {
                         const double ut = uw[t];
-                        double ru = 0.0;
-                        if constexpr (FIX) {
-#pragma unroll
-                            for (int k = 0; k < NUC; ++k) ru = __builtin_fma(rw_[k], uw[k], ru);
-                        } else ru = ldot(sh + p.so.R + t * nu, 1, uw, 1, nu);
-                        cost = __builtin_fma(ut, ru, cost);
+                        cost = __builtin_fma(ut, ldot(sh + p.so.R + t * nu, 1, uw, 1, nu), cost);
                         if (p.U) p.U[((long long)t * p.T + step) * Bsz + b] = ut;
                     }
                     ldsd *sw = cur; cur = nxt; nxt = sw;
@@ -887,7 +876,6 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
                 }
             };
             if (nx == 8 && nu == 4) interior(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
-            else if (nx == 4 && nu == 2) interior(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
             else interior(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
             if (cur != xs) {                                          // uniform: the general path expects the state in the first half
                 __syncthreads();
