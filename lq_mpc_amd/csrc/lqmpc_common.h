@@ -58,6 +58,14 @@ __device__ __forceinline__ double frcp(double x)
     return r;
 }
 
+// one Newton step on the hardware seed (~2^-26 -> ~2^-52): for the pivots of the Gauss-Jordan eliminations, where the reciprocal
+// only scales a row and its last bit does not matter
+__device__ __forceinline__ double frcp1(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+}
+
 __device__ __forceinline__ double frsqrt(double x)
 {
     double y = __builtin_amdgcn_rsq(x);

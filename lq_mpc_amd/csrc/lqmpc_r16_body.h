@@ -152,7 +152,7 @@ __device__ __forceinline__ void gj_invert_step(double (&M)[RB][n], const int (&r
     isettle<LPI>(M[sk][K]);
     const double d = ibcast<LPI>(M[sk][K], lk);
     spd = spd && (d > 0.0);
-    const double inv = frcp(d);
+    const double inv = frcp1(d);
     double g[RB];
 #pragma unroll
     for (int s = 0; s < RB; ++s) {
@@ -631,7 +631,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                                 isettle<LPI>(S[k]);
                                 const double d = ibcast<LPI>(S[k], k);
                                 ok = ok && (d > 0.0);
-                                const double inv = frcp(d);
+                                const double inv = frcp1(d);
                                 const double g = (i == k) ? (inv - 1.0) : -S[k] * inv;
 #pragma unroll
                                 for (int jg = 0; jg < CS / 4; ++jg) {
@@ -766,7 +766,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                                 isettle<LPI>(S[k]);
                                 const double d = ibcast<LPI>(S[k], k);
                                 ok = ok && (d > 0.0);
-                                const double inv = frcp(d);
+                                const double inv = frcp1(d);
                                 const double g = (i == k) ? (inv - 1.0) : -S[k] * inv;
 #pragma unroll
                                 for (int jg = 0; jg < CS / 4; ++jg) {
@@ -892,7 +892,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                         if (k < cw) {
                             const double d = ibcast<LPI>(S[k], k);
                             ok = ok && (d > 0.0);
-                            const double inv = frcp(d);
+                            const double inv = frcp1(d);
                             const double g = (i == k) ? (inv - 1.0) : -S[k] * inv;
 #pragma unroll
                             for (int jg = 0; jg < CS / 4; ++jg) {
@@ -1021,7 +1021,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                         isettle<LPI>(S[k]);
                         const double d = ibcast<LPI>(S[k], k);
                         ok = ok && (d > 0.0);
-                        const double inv = frcp(d);
+                        const double inv = frcp1(d);
                         const double g = (i == k) ? (inv - 1.0) : -S[k] * inv;
 #pragma unroll
                         for (int jg = 0; jg < CS / 4; ++jg) {    // columns in groups of four: one uniform test per group
