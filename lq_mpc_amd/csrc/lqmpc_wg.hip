@@ -301,7 +301,9 @@ struct Wg {
         __syncthreads();
         // The powers of A by doubling, A^(L+i) = A^L A^i for i = 1..L (log2 N dependent levels instead of N: every level is
         // a barrier and a latency-bound dot product with one wavefront per SIMD), then all M_m = A^m B at once.
-        {
+        auto powers = [&](auto nxc, auto nuc) {
+            const int nx = decltype(nxc)::value ? decltype(nxc)::value : this->nx;
+            const int nu = decltype(nuc)::value ? decltype(nuc)::value : this->nu;
             auto ma_row = [&](int m, int u) { const int i = (N - 1 - m) * nu + u; return Ma + (i / BS) * BLK + (i % BS) * LD; };
             const int nn = nx * nx, nb_ = nx * nu;
             for (int e = t; e < nn; e += THREADS) Xf[e] = Am[e];                      // Xf[m] = A^(m+1)
@@ -320,7 +322,9 @@ struct Wg {
                 ma_row(m1 + 1, c)[x] = ldot(Xf + m1 * nn + x * nx, 1, Bm + c, nu, nx);
             }
             __syncthreads();
-        }
+        };
+        if (nx == 8 && nu == 4) powers(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
+        else powers(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         PROF(0);
         const int wave = t >> 6;
         // Cq = Ma (Q Ma)' into the lower blocks of K
@@ -438,10 +442,59 @@ struct Wg {
         ldsd *Am = lds + o.AB, *Bm = Am + nx * nx;
         const ldsd *sh = shd();
         const int wave = t >> 6;
-        // Fq = 2 Gamma' Qbar Phi by the costate recursion on matrices:
-        //   Lam_N = P_T A^N,  Lam_k = Q A^k + A' Lam_{k+1},  Fq block row bi = 2 B' Lam_{bi+1}
-        // (rows of Fq are written one step behind the recursion by a second group of threads)
-        {
+        // Fq = 2 Gamma' Qbar Phi from the costate matrices  Lam_N = P_T A^N,  Lam_k = Q A^k + A' Lam_{k+1}:
+        //   Fq block row bi = 2 B' Lam_{bi+1}.
+        // Unrolled, Lam_k = sum_{j >= k} (A')^(j-k) W_j A^j (W_N = P_T, W_j = Q): partial sums of length L double by
+        //   S_k <- S_k + (A^L)' S_{k+L}
+        // -- log2 N levels of independent nx x nx products (the powers of A are in Xf) instead of N dependent stages, each a barrier
+        // and two latency-bound dot products with one wavefront per SIMD.  S lives in the Linv region (free between the condensing
+        // and the factorisation) when N nx^2 doubles fit there; updated in place, each thread's results held back over a barrier.
+        // (compile-time nx, nu for the C5 shape: constant strides turn every dot product's address arithmetic into immediates --
+        // with one wavefront per SIMD these phases are bound by instruction issue, not by the LDS)
+        auto fq_doubling = [&](auto nxc, auto nuc) {
+            const int nx = decltype(nxc)::value ? decltype(nxc)::value : this->nx;
+            const int nu = decltype(nuc)::value ? decltype(nuc)::value : this->nu;
+            const int nn = nx * nx;
+            ldsd *S = lds + o.Linv;
+            const int dk = THREADS / nn, dr = THREADS % nn;          // e -> e + THREADS: (k1, r) -> (k1 + dk, r + dr) with carry
+            for (int e = t; e < N * nn; e += THREADS) {
+                const int k1 = e / nn, r = e - k1 * nn, x = r / nx, y = r - x * nx;
+                S[e] = ldot(sh + ((k1 == N - 1) ? p.so.P : p.so.Q) + x * nx, 1, Xf + k1 * nn + y, nx, nx);      // W_k A^k, k = k1 + 1
+            }
+            __syncthreads();
+            for (int L = 1; L < N; L *= 2) {
+                const ldsd *AL = Xf + (L - 1) * nn;
+                const int total = (N - L) * nn;
+                for (int c0 = 0; c0 < total; c0 += 8 * THREADS) {
+                    double v[8];
+                    int k1 = (c0 + t) / nn, r = (c0 + t) - k1 * nn, x = r / nx, y = r - x * nx;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = c0 + q * THREADS + t;
+                        v[q] = (e < total) ? ldot(AL + x, nx, S + (k1 + L) * nn + y, nx, nx, S[e]) : 0.0;
+                        k1 += dk; r += dr;
+                        if (dr) { if (r >= nn) { r -= nn; ++k1; } x = r / nx; y = r - x * nx; }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = c0 + q * THREADS + t;
+                        if (e < total) S[e] = v[q];
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int e = t; e < N * nu * nx; e += THREADS) {
+                const int i = e / nx, a = e - i * nx, bi = i / nu, ui = i - bi * nu;
+                X[(i / BS) * BLK + (i % BS) * LD + a] = 2.0 * ldot(Bm + ui, nu, S + bi * nn + a, nx, nx);
+            }
+            __syncthreads();
+        };
+        if (N * nx * nx <= nb * BLK) {
+            if (nx == 8 && nu == 4) fq_doubling(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
+            else fq_doubling(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        } else {
+            // (the same by the recursion itself; rows of Fq are written one step behind it by a second group of threads)
             const bool mine = t < nx * nx;
             const int x = mine ? t / nx : 0, y = mine ? t % nx : 0;
             const int t2 = t - 64;

@@ -6,14 +6,14 @@
 // access patterns of v_mfma_f64_16x16x4_f64 cheap: its A/B operand fetch (lane -> element [lane%16][4t +
 // lane/16]) and its C/D tile (lane -> rows lane/16 + 4r, column lane%16).
 //
-// chol_blocked(): right-looking blocked Cholesky.  Per block column kb:
-//   wave 0 factors the 16x16 diagonal block with one matrix row per lane (v_readlane broadcasts) and
-//   inverts it; barrier; the panel blocks X = A L_kk^-T are formed as matrix products with the inverse and
-//   the trailing blocks A_ij -= L_ik L_jk' as rank-16 updates, both on the f64 MFMA, block products dealt
-//   round-robin to the 4 waves; barrier.  16 barriers per factorisation of n = 128.
+// chol_blocked(): right-looking blocked Cholesky with look-ahead.  Per block column kb: the panel blocks X = A L_kk^-T are
+//   formed as matrix products with the inverse of the diagonal block (4 waves); barrier; in the trailing update A_ij -= L_ik L_jk'
+//   (rank-16 updates on the f64 MFMA) wave 0 takes the next diagonal block only, then factors it with one matrix row per lane (DPP
+//   row broadcasts) and inverts it in the same pass, while waves 1..3 update the rest; barrier.
 // After it: strict lower blocks hold L, diagonal blocks hold L_kk (lower triangle), Linv holds L_kk^-1.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "lqmpc_common.h"
 
 namespace lqmpc {
@@ -39,6 +39,11 @@ __device__ __forceinline__ double rdlane(double x, int src)
     return __hiloint2double(hi, lo);
 }
 
+// Arguments of a non-inlined device function arrive in vector registers and count as divergent: every loop on them would run under
+// exec masks with its block addresses on the vector ALU (v_mad_u64_u32 ...).  They are workgroup-uniform here; say so.
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+template <class T> __device__ __forceinline__ T *uni(T *p) { return (T *)(size_t)__builtin_amdgcn_readfirstlane((int)(size_t)p); }
+
 // D = C +- op(X) * op(Y)'  for 16x16 blocks X, Y in LDS (row stride LD), op = identity or transpose.
 // C/D in the MFMA tile layout (element r of the result: row lane/16 + 4r, column lane%16).  One wave.
 // Operand fetch of v_mfma_f64_16x16x4_f64: lane l supplies A[l%16][4t + l/16] and B'[l%16][4t + l/16].
@@ -57,6 +62,48 @@ __device__ __forceinline__ d4_t block_mm(const ldsd *X, const ldsd *Y, d4_t c, b
     return c;
 }
 __device__ __forceinline__ d4_t block_xyt(const ldsd *X, const ldsd *Y, d4_t c, bool negate) { return block_mm<false, false>(X, Y, c, negate); }
+
+// The operands of one block product as the MFMA wants them (8 doubles per lane), so that a sum of products can fetch the next
+// pair of blocks while the matrix core works on the current one (one wavefront per SIMD here: nothing else hides the LDS trip).
+struct BOps { double a[4], b[4]; };
+template <bool XT, bool YT>
+__device__ __forceinline__ void load_ops(const ldsd *X, const ldsd *Y, BOps &o)
+{
+    const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        o.a[t] = XT ? X[(4 * t + kq) * LD + i] : X[i * LD + 4 * t + kq];
+        o.b[t] = YT ? Y[(4 * t + kq) * LD + i] : Y[i * LD + 4 * t + kq];
+    }
+}
+__device__ __forceinline__ d4_t mfma_ops(const BOps &o, d4_t c, bool negate)
+{
+#pragma unroll
+    for (int t = 0; t < 4; ++t) c = __builtin_amdgcn_mfma_f64_16x16x4f64(negate ? -o.a[t] : o.a[t], o.b[t], c, 0, 0, 0);
+    return c;
+}
+// c +- sum_{m = m0 .. m1-1} op(X(m)) op(Y(m))', the loads of product m+1 issued before the MFMAs of product m
+template <bool XT, bool YT, class FX, class FY>
+__device__ __forceinline__ d4_t block_sum(int m0, int m1, FX X, FY Y, d4_t c, bool negate)
+{
+    if (m0 >= m1) return c;
+    BOps cur, nxt;
+    load_ops<XT, YT>(X(m0), Y(m0), cur);
+    for (int m = m0; m < m1; m += 2) {                           // two products per round: the operand sets ping-pong, no copies
+        const int mn = (m + 1 < m1) ? m + 1 : m;                 // (an odd tail re-reads its own operands: harmless)
+        load_ops<XT, YT>(X(mn), Y(mn), nxt);
+        __builtin_amdgcn_sched_barrier(0);                       // (the scheduler otherwise sinks the loads to their first use)
+        c = mfma_ops(cur, c, negate);
+        __builtin_amdgcn_sched_barrier(0);
+        if (m + 1 >= m1) break;
+        const int mc = (m + 2 < m1) ? m + 2 : m + 1;
+        load_ops<XT, YT>(X(mc), Y(mc), cur);
+        __builtin_amdgcn_sched_barrier(0);
+        c = mfma_ops(nxt, c, negate);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return c;
+}
 
 __device__ __forceinline__ d4_t tile_load(const ldsd *C)
 {
@@ -142,6 +189,23 @@ __device__ __forceinline__ void fmac_rowb_self4(double &a0, double &a1, double &
     }
 }
 
+// a_j += (lane c0+j's x, broadcast over the row) * y for four consecutive lanes c0 .. c0+3 behind one s_nop: four columns of the
+// factorisation's update a_ic -= l_ik l_ck (x = the pivot column, one entry per lane; y = -l_ik)
+#define LQMPC_COLS4_CASES(X) X(0, 1, 2, 3) X(1, 2, 3, 4) X(2, 3, 4, 5) X(3, 4, 5, 6) X(4, 5, 6, 7) X(5, 6, 7, 8) X(6, 7, 8, 9) X(7, 8, 9, 10) \
+    X(8, 9, 10, 11) X(9, 10, 11, 12) X(10, 11, 12, 13) X(11, 12, 13, 14) X(12, 13, 14, 15)
+__device__ __forceinline__ void fmac_rowb_cols4(double &a0, double &a1, double &a2, double &a3, double x, double y, int c0)
+{
+    switch (c0) {
+#define LQMPC_X(C0, C1, C2, C3) case C0: asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %4, %5 row_newbcast:" #C0 " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %1, %4, %5 row_newbcast:" #C1 " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %2, %4, %5 row_newbcast:" #C2 " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %3, %4, %5 row_newbcast:" #C3 " row_mask:0xf bank_mask:0xf" \
+                                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x), "v"(y)); break;
+        LQMPC_COLS4_CASES(LQMPC_X)
+#undef LQMPC_X
+    }
+}
+
 // two wait states tied to x: a DPP read of x that follows in program order is safe even if x was written by
 // the inline asm right before (the compiler's hazard recogniser does not see those writes)
 __device__ __forceinline__ void dpp_settle(double &x) { asm volatile("s_nop 1" : "+v"(x)); }
@@ -154,49 +218,66 @@ __device__ __forceinline__ double frsqrt1(double x)
     return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
 }
 
+// compile-time loop: f(integral_constant<int, I>) for I = I0 .. I1-1.  The pivot loops below use it instead of "#pragma unroll" because
+// the unroller prices the lane switch of every rowb helper at all 16 cases and then refuses to unroll fully -- which would leave the
+// row registers indexed at run time (s_set_gpr_idx) and every broadcast behind a jump table.
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I0 < I1) { f(std::integral_constant<int, I0>{}); static_for<I0 + 1, I1>(f); }
+}
+
 // One wave: factor the diagonal block D (in place: lower triangle <- L, upper <- 0) and write its inverse
 // (lower triangular) to Dinv.  Returns false on a non-positive pivot.
-//   factor:  one matrix row per lane (lanes 16..63 mirror lanes 0..15); per column k: broadcast the pivot,
-//            rsqrt, scale, then one v_fmac_f64_dpp per remaining column (row_newbcast brings l_ck) --
-//            16 dependent steps, each one rsqrt chain long;
-//   inverse: L goes to LDS, then lane j solves L z = e_j by forward substitution; every L_ik it needs is the
-//            same for all lanes, i.e. a broadcast LDS read, and nothing crosses lanes.
+// One matrix row per lane (lanes 16..63 mirror lanes 0..15).  Per column k: broadcast the pivot, rsqrt, scale, then one
+// v_fmac_f64_dpp per remaining column (row_newbcast brings l_ck) -- 16 dependent steps, each one rsqrt chain long.  The inverse
+// rides in the shadow of that chain: the same row operations applied to the identity (row i of Z = L^-1 in lane i),
+//     z_k <- s_k z_k,   z_i <- z_i - l_ik z_k  (i > k),
+// are one v_fmac_f64_dpp per entry of z_k with the per-lane multiplier m_i = (i == k) ? s_k - 1 : (i > k) ? -l_ik s_k : 0 and need
+// neither LDS nor the finished L (k + 1 entries at step k: 136 updates, issued while the next pivot's rsqrt is in flight).
 __device__ __forceinline__ bool diag_factor_invert(ldsd *D, ldsd *Dinv)
 {
     const int lane = threadIdx.x & 63;
     const int i = lane & 15;
-    double row[BS], sinv[BS];
+    double row[BS], z[BS];
 #pragma unroll
-    for (int j = 0; j < BS; ++j) row[j] = D[i * LD + j];
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < BS; ++k) {
-        const double d = rowb(row[k], k);
-        ok = ok && (d > 0.0);
-        const double s = frsqrt1(d);
-        sinv[k] = s;
+    for (int j = 0; j < BS; ++j) { row[j] = D[i * LD + j]; z[j] = (j == i) ? 1.0 : 0.0; }
+    double d = rowb(row[0], 0);
+    bool ok = d > 0.0;
+    double y = __builtin_amdgcn_rsq(d);
+    static_for<0, BS>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        // the chain: pivot k's rsqrt (issued one step ago) -> l_.k -> column k+1 -> pivot k+1 -> its rsqrt
+        const double e = __builtin_fma(-d * y, y, 1.0);
+        const double s = __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
         row[k] *= s;                                             // l_kk = d / sqrt(d) in lane k, l_ik = a_ik / l_kk below it
         const double nl = -row[k];
-#pragma unroll
-        for (int c = k + 1; c < BS; ++c) fmac_rowb(row[c], row[k], nl, c);   // a_ic -= l_ik l_ck
-    }
+        const double m = (i == k) ? s - 1.0 : ((i > k) ? nl * s : 0.0);
+        if constexpr (k + 1 < BS) {
+            fmac_rowb(row[k + 1], row[k], nl, k + 1);            // a_i,k+1 -= l_ik l_k+1,k
+            dpp_settle(row[k + 1]);
+            d = rowb(row[k + 1], k + 1);
+            ok = ok && (d > 0.0);
+            y = __builtin_amdgcn_rsq(d);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // in the shadow of that rsqrt: the other columns (a_ic -= l_ik l_ck) and the inverse's rows (z_k <- s z_k, z_i -= l_ik z_k)
+        constexpr int G = (BS - k - 2 > 0) ? (BS - k - 2) / 4 : 0;
+        static_for<0, G>([&](auto gc) {
+            constexpr int c = k + 2 + 4 * decltype(gc)::value;
+            fmac_rowb_cols4(row[c], row[c + 1], row[c + 2], row[c + 3], row[k], nl, c);
+        });
+        static_for<k + 2 + 4 * G, BS>([&](auto cc) { constexpr int c = decltype(cc)::value; fmac_rowb(row[c], row[k], nl, c); });
+        static_for<0, (k + 1) / 4>([&](auto gc) {
+            constexpr int j = 4 * decltype(gc)::value;
+            fmac_rowb_self4(z[j], z[j + 1], z[j + 2], z[j + 3], m, k);
+        });
+        static_for<((k + 1) / 4) * 4, k + 1>([&](auto jc) { fmac_rowb_self(z[decltype(jc)::value], m, k); });
+        __builtin_amdgcn_sched_barrier(0);
+    });
     if (lane < BS) {
 #pragma unroll
-        for (int j = 0; j < BS; ++j) D[i * LD + j] = (j <= i) ? row[j] : 0.0;
-    }
-    __builtin_amdgcn_wave_barrier();
-    double z[BS];                                                // column i of L^-1: z_r = (delta_ri - sum_{k<r} l_rk z_k) / l_rr
-#pragma unroll
-    for (int r = 0; r < BS; ++r) z[r] = (r == i) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < BS; ++k) {
-        z[k] *= sinv[k];
-#pragma unroll
-        for (int r = k + 1; r < BS; ++r) z[r] = __builtin_fma(-D[r * LD + k], z[k], z[r]);   // independent across r
-    }
-    if (lane < BS) {
-#pragma unroll
-        for (int r = 0; r < BS; ++r) Dinv[r * LD + i] = z[r];
+        for (int j = 0; j < BS; ++j) { D[i * LD + j] = (j <= i) ? row[j] : 0.0; Dinv[i * LD + j] = z[j]; }
     }
     return ok;
 }
@@ -204,66 +285,87 @@ __device__ __forceinline__ bool diag_factor_invert(ldsd *D, ldsd *Dinv)
 // One wave: solve S x = r for an m x m SPD system, m <= 16, S in one block (row stride LD, rows/columns >= m
 // hold the identity), r and x in LDS (x may alias r).  T: a block of LDS scratch.  Returns false on a
 // non-positive pivot.  Row per lane; the forward substitution rides along with the factorisation, the
-// backward one uses the transpose of L fetched back from T.
-__device__ __forceinline__ bool small_spd_solve(const ldsd *S, ldsd *T, const ldsd *r, ldsd *x, int m)
+// backward one uses the transpose of L fetched back from T.  Compiled for MB = 4, 8, 12, 16 pivots (the identity rows up to MB
+// factor to themselves), so that no update sits behind a branch on m; the chain is pipelined as in diag_factor_invert.
+template <int MB>
+__device__ __forceinline__ bool small_spd_solve_mb(const ldsd *S, ldsd *T, const ldsd *r, ldsd *x, int m)
 {
     const int lane = threadIdx.x & 63;
     const int i = lane & 15;
-    double row[BS], sinv[BS], lt[BS];
+    double row[MB], sinv[MB], lt[MB];
 #pragma unroll
-    for (int j = 0; j < BS; ++j) row[j] = S[i * LD + j];
-    double acc = r[i], y = 0.0;
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < BS; ++k) {
-        sinv[k] = 1.0;
-        if (k < m) {                                             // uniform
-            const double d = rowb(row[k], k);
+    for (int j = 0; j < MB; ++j) row[j] = S[i * LD + j];
+    double acc = r[i], ysol = 0.0;
+    double d = rowb(row[0], 0);
+    bool ok = d > 0.0;
+    double y = __builtin_amdgcn_rsq(d);
+    static_for<0, MB>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const double e = __builtin_fma(-d * y, y, 1.0);
+        const double s = __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
+        sinv[k] = s;
+        row[k] *= s;
+        const double nl = -row[k];
+        if constexpr (k + 1 < MB) {
+            fmac_rowb(row[k + 1], row[k], nl, k + 1);
+            dpp_settle(row[k + 1]);
+            d = rowb(row[k + 1], k + 1);
             ok = ok && (d > 0.0);
-            const double s = frsqrt1(d);
-            sinv[k] = s;
-            row[k] *= s;
-            const double nl = -row[k];
-            const double yk = rowb(acc, k) * s;                  // forward substitution, column k
-            y = (i == k) ? yk : y;
-            acc = __builtin_fma(nl, yk, acc);
-    #pragma unroll
-            for (int c = k + 1; c < BS; ++c)
-                if (c < m) fmac_rowb(row[c], row[k], nl, c);
+            y = __builtin_amdgcn_rsq(d);
         }
-    }
+        __builtin_amdgcn_sched_barrier(0);
+        const double yk = rowb(acc, k) * s;                      // forward substitution, column k
+        ysol = (i == k) ? yk : ysol;
+        acc = __builtin_fma(nl, yk, acc);
+        constexpr int G = (MB - k - 2 > 0) ? (MB - k - 2) / 4 : 0;
+        static_for<0, G>([&](auto gc) {
+            constexpr int c = k + 2 + 4 * decltype(gc)::value;
+            fmac_rowb_cols4(row[c], row[c + 1], row[c + 2], row[c + 3], row[k], nl, c);
+        });
+        static_for<k + 2 + 4 * G, MB>([&](auto cc) { constexpr int c = decltype(cc)::value; fmac_rowb(row[c], row[k], nl, c); });
+        __builtin_amdgcn_sched_barrier(0);
+    });
     if (lane < BS) {
 #pragma unroll
-        for (int j = 0; j < BS; ++j) T[i * LD + j] = row[j];
+        for (int j = 0; j < MB; ++j) T[i * LD + j] = row[j];
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k = 0; k < BS; ++k) lt[k] = T[k * LD + i];          // L[k][lane]
+    for (int k = 0; k < MB; ++k) lt[k] = T[k * LD + i];          // L[k][lane]
     double xs = 0.0;
-    acc = y;
-#pragma unroll
-    for (int k = BS - 1; k >= 0; --k) {
-        if (k < m) {
-            const double xk = rowb(acc, k) * sinv[k];
-            xs = (i == k) ? xk : xs;
-            acc = __builtin_fma(-lt[k], xk, acc);                // lanes j < k: y_j - sum_{r > j} l_rj x_r
-        }
-    }
+    acc = ysol;
+    static_for<0, MB>([&](auto kc) {
+        constexpr int k = MB - 1 - decltype(kc)::value;
+        const double xk = rowb(acc, k) * sinv[k];
+        xs = (i == k) ? xk : xs;
+        acc = __builtin_fma(-lt[k], xk, acc);                    // lanes j < k: y_j - sum_{r > j} l_rj x_r
+    });
     if (lane < BS) x[i] = (i < m) ? xs : 0.0;
     return ok;
 }
+__device__ __forceinline__ bool small_spd_solve(const ldsd *S, ldsd *T, const ldsd *r, ldsd *x, int m)
+{
+    if (m <= 4) return small_spd_solve_mb<4>(S, T, r, x, m);     // uniform
+    if (m <= 8) return small_spd_solve_mb<8>(S, T, r, x, m);
+    if (m <= 12) return small_spd_solve_mb<12>(S, T, r, x, m);
+    return small_spd_solve_mb<16>(S, T, r, x, m);
+}
 
 // Blocked Cholesky of the nb x nb block matrix at K (LDS); Linv: nb diagonal-block inverses.  All 256 threads.
+// Right-looking with look-ahead: in the trailing update of block column kb wave 0 takes the next diagonal block only and goes
+// straight on to factor and invert it (the 16-pivot chain is the critical path of the whole factorisation), waves 1..3 share the
+// other blocks, operands of the next block fetched while the matrix core works on the current one.  Two barriers per block column.
 __device__ __noinline__ bool chol_blocked(ldsd *K, ldsd *Linv, int nb, ldsi *flag)
 {
-    const int wave = threadIdx.x >> 6;
+    K = uni(K); Linv = uni(Linv); nb = uni(nb); flag = uni(flag);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform: loops and block addresses on the scalar unit
     if (threadIdx.x == 0) *flag = 1;
-    for (int kb = 0; kb < nb; ++kb) {
-        __syncthreads();
-        if (wave == 0) {
-            const bool ok = diag_factor_invert(K + blk_index(kb, kb) * BLK, Linv + kb * BLK);
-            if (!ok && (threadIdx.x & 63) == 0) *flag = 0;
-        }
+    __syncthreads();
+    if (wave == 0) {
+        const bool ok = diag_factor_invert(K, Linv);
+        if (!ok && (threadIdx.x & 63) == 0) *flag = 0;
+    }
+    for (int kb = 0; kb < nb - 1; ++kb) {
         __syncthreads();
         // panel: X_ib = A_ib,kb * Linv_kk'   (ib > kb), in place
         for (int ib = kb + 1 + wave; ib < nb; ib += 4) {
@@ -274,15 +376,35 @@ __device__ __noinline__ bool chol_blocked(ldsd *K, ldsd *Linv, int nb, ldsi *fla
         }
         __syncthreads();
         // trailing update: A_ib,jb -= X_ib X_jb'   (kb < jb <= ib)
-        int cnt = 0;
-        for (int ib = kb + 1; ib < nb; ++ib)
-            for (int jb = kb + 1; jb <= ib; ++jb, ++cnt) {
-                if ((cnt & 3) != wave) continue;
-                ldsd *C = K + blk_index(ib, jb) * BLK;
-                d4_t c = tile_load(C);
-                c = block_xyt(K + blk_index(ib, kb) * BLK, K + blk_index(jb, kb) * BLK, c, true);
-                tile_store(C, c);
+        if (wave == 0) {
+            ldsd *C = K + blk_index(kb + 1, kb + 1) * BLK, *X = K + blk_index(kb + 1, kb) * BLK;
+            d4_t c = tile_load(C);
+            c = block_xyt(X, X, c, true);
+            tile_store(C, c);
+            const bool ok = diag_factor_invert(C, Linv + (kb + 1) * BLK);
+            if (!ok && (threadIdx.x & 63) == 0) *flag = 0;
+        } else {
+            auto step = [&](int &ib, int &jb, int cnt) { for (int q = 0; q < cnt; ++q) if (++jb > ib) { ++ib; jb = kb + 1; } };
+            int ib = kb + 1, jb = kb + 1;
+            step(ib, jb, wave);                                  // blocks 1, 2, 3 (+ 3 each round) of the trailing triangle in storage order
+            if (ib < nb) {
+                BOps cur, nxt;
+                load_ops<false, false>(K + blk_index(ib, kb) * BLK, K + blk_index(jb, kb) * BLK, cur);
+                d4_t cc = tile_load(K + blk_index(ib, jb) * BLK), cn;
+                while (ib < nb) {
+                    int ib2 = ib, jb2 = jb;
+                    step(ib2, jb2, 3);
+                    const int ibn = (ib2 < nb) ? ib2 : ib, jbn = (ib2 < nb) ? jb2 : jb;      // (the last round re-reads its own block)
+                    load_ops<false, false>(K + blk_index(ibn, kb) * BLK, K + blk_index(jbn, kb) * BLK, nxt);
+                    cn = tile_load(K + blk_index(ibn, jbn) * BLK);
+                    __builtin_amdgcn_sched_barrier(0);
+                    cc = mfma_ops(cur, cc, true);
+                    __builtin_amdgcn_sched_barrier(0);
+                    tile_store(K + blk_index(ib, jb) * BLK, cc);
+                    cur = nxt; cc = cn; ib = ib2; jb = jb2;
+                }
             }
+        }
     }
     __syncthreads();
     return *flag != 0;
@@ -291,6 +413,7 @@ __device__ __noinline__ bool chol_blocked(ldsd *K, ldsd *Linv, int nb, ldsi *fla
 // Solve (L L') x = b.  b: LDS vector of nb*16 doubles (in place).  tmp: LDS scratch of 16 doubles.
 __device__ __noinline__ void solve_blocked(const ldsd *K, const ldsd *Linv, int nb, ldsd *b)
 {
+    K = uni(K); Linv = uni(Linv); nb = uni(nb); b = uni(b);
     const int t = threadIdx.x;
     // forward: y_kb = Linv_kk b_kb ; b_ib -= L_ib,kb y_kb
     for (int kb = 0; kb < nb; ++kb) {
@@ -340,9 +463,11 @@ __device__ __noinline__ void solve_blocked(const ldsd *K, const ldsd *Linv, int 
 
 // In place Z = L^-1 for the blocked factor at K (diagonal-block inverses in Linv), right to left by block
 // column:  X_m = L_mj Z_jj (m > j);  Z_ij = -sum_{m=j+1..i} Z_im X_mj.  All 256 threads; nb <= 8.
+// The sums are pipelined (block_sum) and dealt so that a wave gets a short and a long one (i - j products for block row i).
 __device__ __noinline__ void tri_invert_blocked(ldsd *K, const ldsd *Linv, int nb)
 {
-    const int wave = threadIdx.x >> 6;
+    K = uni(K); Linv = uni(Linv); nb = uni(nb);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform: loops and block addresses on the scalar unit
     for (int j = nb - 1; j >= 0; --j) {
         __syncthreads();
         for (int m = j + 1 + wave; m < nb; m += 4) {                 // X_m = L_mj * Z_jj, in place
@@ -354,19 +479,17 @@ __device__ __noinline__ void tri_invert_blocked(ldsd *K, const ldsd *Linv, int n
         __syncthreads();
         auto zij = [&](int i) {
             d4_t c = {0.0, 0.0, 0.0, 0.0};
-            for (int m = j + 1; m <= i; ++m) {
-                const ldsd *Z = (m == i) ? Linv + i * BLK : K + blk_index(i, m) * BLK;
-                c = block_mm<false, true>(Z, K + blk_index(m, j) * BLK, c, true);
-            }
-            return c;
+            return block_sum<false, true>(j + 1, i + 1,
+                                          [&](int m) { return (m == i) ? Linv + i * BLK : K + blk_index(i, m) * BLK; },
+                                          [&](int m) { return K + blk_index(m, j) * BLK; }, c, true);
         };
-        const int i0 = j + 1 + wave, i1 = i0 + 4;                    // nb <= 8: at most two blocks per wave
+        const int i0 = j + 1 + wave, i1 = nb - 1 - wave;             // nb <= 8: block rows j+1 .. nb-1 are covered by 4 such pairs
         d4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0;
-        if (i0 < nb) a0 = zij(i0);
-        if (i1 < nb) a1 = zij(i1);
+        if (i0 <= i1) a0 = zij(i0);
+        if (i0 < i1) a1 = zij(i1);
         __syncthreads();
-        if (i0 < nb) tile_store(K + blk_index(i0, j) * BLK, a0);
-        if (i1 < nb) tile_store(K + blk_index(i1, j) * BLK, a1);
+        if (i0 <= i1) tile_store(K + blk_index(i0, j) * BLK, a0);
+        if (i0 < i1) tile_store(K + blk_index(i1, j) * BLK, a1);
     }
     __syncthreads();
     for (int e = threadIdx.x; e < nb * BLK; e += THREADS) {          // diagonal blocks of Z
@@ -377,25 +500,40 @@ __device__ __noinline__ void tri_invert_blocked(ldsd *K, const ldsd *Linv, int n
 }
 
 // In place W = Z'Z (= (L L')^-1) for the lower-triangular block matrix Z at K; diagonal blocks of W come
-// out full (both triangles).  Block row i of W needs block rows >= i of Z only: ascending i, in place.
+// out full (both triangles).  W_ij = sum_{k >= i} Z_ki' Z_kj (j <= i): every block of W is computed from Z before any is
+// stored -- 36 blocks at nb = 8, nine accumulators per wave (dealt round-robin in storage order: 33 / 31 / 29 / 27 products)
+// -- so the whole product costs two barriers.
+#ifndef LQMPC_ZTZ_T
+#define LQMPC_ZTZ_T(k) do { } while (0)
+#endif
+constexpr int ZTZ_SLOTS = 9;             // ceil(36 / 4)
 __device__ __noinline__ void ztz_blocked(ldsd *K, int nb)
 {
-    const int wave = threadIdx.x >> 6;
-    for (int i = 0; i < nb; ++i) {
-        auto wij = [&](int j) {
-            d4_t c = {0.0, 0.0, 0.0, 0.0};
-            for (int k = i; k < nb; ++k) c = block_mm<true, true>(K + blk_index(k, i) * BLK, K + blk_index(k, j) * BLK, c, false);
-            return c;
-        };
-        const int j0 = wave, j1 = wave + 4;
-        d4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0;
-        if (j0 <= i) a0 = wij(j0);
-        if (j1 <= i) a1 = wij(j1);
-        __syncthreads();
-        if (j0 <= i) tile_store(K + blk_index(i, j0) * BLK, a0);
-        if (j1 <= i) tile_store(K + blk_index(i, j1) * BLK, a1);
-        __syncthreads();
+    K = uni(K); nb = uni(nb);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform: loops and block addresses on the scalar unit
+    const int nblk = nb * (nb + 1) / 2;
+    d4_t acc[ZTZ_SLOTS];
+    LQMPC_ZTZ_T(0);
+    {
+        int i = 0, j = 0;                                            // block (i, j) of storage index q
+        for (int s = 0; s < wave; ++s) { if (++j > i) { ++i; j = 0; } }
+#pragma unroll
+        for (int s = 0; s < ZTZ_SLOTS; ++s) {
+            acc[s] = d4_t{0.0, 0.0, 0.0, 0.0};
+            if (wave + 4 * s < nblk)
+                acc[s] = block_sum<true, true>(i, nb, [&](int k) { return K + blk_index(k, i) * BLK; },
+                                               [&](int k) { return K + blk_index(k, j) * BLK; }, acc[s], false);
+            for (int r = 0; r < 4; ++r) { if (++j > i) { ++i; j = 0; } }
+        }
     }
+    LQMPC_ZTZ_T(1);
+    __syncthreads();
+    LQMPC_ZTZ_T(2);
+#pragma unroll
+    for (int s = 0; s < ZTZ_SLOTS; ++s)
+        if (wave + 4 * s < nblk) tile_store(K + (wave + 4 * s) * BLK, acc[s]);
+    __syncthreads();
+    LQMPC_ZTZ_T(3);
 }
 
 }  // namespace wg

@@ -39,4 +39,4 @@ for nb, ninst, ms_ in ((1, 4, 16), (3, 4, 7), (8, 4, 11), (8, 2048, 5), (8, 2048
         Wfull = unpack(Wo[i], nb); d = max(np.abs(Wfull[k*BS:(k+1)*BS, k*BS:(k+1)*BS] - Wfull[k*BS:(k+1)*BS, k*BS:(k+1)*BS].T).max() for k in range(nb))
         errW = max(errW, d)
         errs = max(errs, np.abs(so[i, :ms_] - np.linalg.solve(Ks[i][:ms_, :ms_], bs[i][:ms_])).max())
-    print(f'nb={nb} n={n} inst={ninst} m={ms_}: rc={rc} ok={ok.min()} |L| {errL:.1e} |x| {errx:.1e} |W| {errW:.1e} |small| {errs:.1e}  {ms.value:.3f} ms; ticks small {cyc[0]} chol {cyc[1]} solve {cyc[2]} triinv {cyc[3]} ztz {cyc[4]}')
+    print(f'nb={nb} n={n} inst={ninst} m={ms_}: rc={rc} ok={ok.min()} |L| {errL:.1e} |x| {errx:.1e} |W| {errW:.1e} |small| {errs:.1e}  {ms.value:.3f} ms; ticks small {cyc[0]} chol {cyc[1]} solve {cyc[2]} triinv {cyc[3]} ztz {cyc[4]} [entry {cyc[5]} sums {cyc[6]} store {cyc[7]}]')

@@ -1,4 +1,6 @@
 // standalone check of lqmpc_wg_linalg.h: blocked MFMA Cholesky / solve / inverse vs numpy (dev tool)
+__device__ long long g_zt[8];
+#define LQMPC_ZTZ_T(k) do { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) g_zt[k] = clock64(); } while (0)
 #include "../../lq_mpc_amd/csrc/lqmpc_wg_linalg.h"
 #include <cstdio>
 using namespace lqmpc;
@@ -10,6 +12,7 @@ __global__ void __launch_bounds__(256) k_test(const double *Kin, const double *b
     extern __shared__ double lds_raw[];
     ldsd *lds = (ldsd *)lds_raw;
     const int nblk = nb * (nb + 1) / 2;
+    unsigned base = (unsigned)(size_t)lds; asm volatile("" : "+s"(base)); lds = (ldsd *)(size_t)base;   // opaque: the helpers must take K as an argument, as in the product kernel (no dynamic-LDS table look-ups)
     ldsd *K = lds, *Linv = K + nblk * BLK, *b = Linv + nb * BLK, *T = b + nb * BS, *S = T + BLK, *sv = S + BLK;
     ldsi *flag = (ldsi *)(sv + BS);
     const long long inst = blockIdx.x;
@@ -35,7 +38,7 @@ __global__ void __launch_bounds__(256) k_test(const double *Kin, const double *b
     long long t6 = clock64();
     ztz_blocked(K, nb);
     long long t7 = clock64();
-    if (threadIdx.x == 0 && blockIdx.x == 0) { g_cyc[0] = t1 - t0; g_cyc[1] = t3 - t2; g_cyc[2] = t5 - t4; g_cyc[3] = t6 - t5; g_cyc[4] = t7 - t6; }
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) { g_cyc[0] = t1 - t0; g_cyc[1] = t3 - t2; g_cyc[2] = t5 - t4; g_cyc[3] = t6 - t5; g_cyc[4] = t7 - t6; g_cyc[5] = g_zt[0] - t6; g_cyc[6] = g_zt[1] - g_zt[0]; g_cyc[7] = g_zt[3] - g_zt[1]; }
     for (int e = threadIdx.x; e < nblk * BLK; e += 256) Wout[inst * nblk * BLK + e] = K[e];
     for (int e = threadIdx.x; e < nb * BS; e += 256) xout[inst * nb * BS + e] = b[e];
     if (threadIdx.x == 0) okout[inst] = (ok && oks) ? 1 : 0;
