@@ -200,11 +200,6 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     constexpr bool PACKED = (OCC == 2);
     using C = R16<NX, NU, N, LPI, PACKED>;
     constexpr int CS = C::CS;
-    // Unrolling of the horizon-length loop of the Fq rows (the powers of A and the diagonal sums are run-time loops with
-    // a few instructions per step).  Fully unrolled it is fastest for N <= 10, but further the scheduler hoists every LDS
-    // load to the top and spills; partly rolled the longer horizons compile without a spill.
-    constexpr bool UNROLL = (N <= 10) && OCC == 1;
-    constexpr int UNR_FQ = UNROLL ? N : 2;
     constexpr int n = C::n, RB = C::RB, LDW = C::LDW;
     constexpr int REC = NX * NX + NX * NU + NX;
     const int lane = threadIdx.x, q = lane / LPI, i = lane % LPI;

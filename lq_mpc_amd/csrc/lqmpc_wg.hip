@@ -262,11 +262,29 @@ struct Wg {
     //           = C1(i, j) + sum_{s>=1} Cq(i + s nu, j + s nu),   C1 = Ma (P_T Ma)', Cq = Ma (Q Ma)',
     // with Ma the n x nx matrix whose row i is column ui of M_a: two block-row products on the MFMA and a
     // suffix sum along the stage diagonals.
-    __device__ __forceinline__ void setup(long long b)
+    __device__ __forceinline__ void setup_impl(long long b)
     {
         stage(b);
         condense_P();
         finish_condensed();
+    }
+    // The C5 shape runs the set-up on a copy of this object whose dimensions and LDS offsets are compile-time constants: with one
+    // wavefront per SIMD its phases are bound by instruction issue, and every run-time stride costs a multiply (or a divide) per
+    // address.  The steps stay on run-time dimensions: with the block counts known the compiler unrolls the row products and gathers
+    // of the active-set iterations over all 8 blocks, spills, and the 30 steps get slower (measured: kernel-wide constants 19.4 ms,
+    // set-up only 18.x ms per C5 launch).
+    __device__ __forceinline__ void setup(long long b)
+    {
+        if (nx == 8 && nu == 4 && N == 30 && n == 120) {
+            Wg c{p, wg_offsets(8, 4, 30), lds, 120, 8, 128, 8, 4, 30, t};
+            c.own = own; c.h = h; c.ctr = ctr; c.vr = 0.0;
+            c.setup_impl(b);
+#pragma unroll
+            for (int m = 0; m < PREG; ++m) preg[m] = c.preg[m];
+            vr = c.vr;
+        } else {
+            setup_impl(b);
+        }
     }
 
     __device__ __forceinline__ void stage(long long b)
@@ -869,38 +887,38 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
             // NaN) leaves everything as it was and takes the general path below.
             ldsd *uw = lds + w.o.vw;
             ldsd *cur = xs, *nxt = xs + nx;                           // the state ping-pongs between the two halves: one barrier per step
-            // (NXC, NUC) > 0: the dimensions at compile time (C5's) -- my row of G and of the plant stay in registers over the
+            // (NXI, NUI) > 0: the dimensions at compile time (C5's) -- my row of G and of the plant stay in registers over the
             // steps and only the state and the inputs go through LDS; (0, 0): run-time dimensions, everything read from LDS per step
             auto interior = [&](auto nxc, auto nuc) {
-                constexpr int NXC = decltype(nxc)::value, NUC = decltype(nuc)::value;
-                constexpr bool FIX = NXC > 0;
-                double g[FIX ? NXC : 1], ar[FIX ? NXC : 1], br[FIX ? NUC : 1];    // (the weights' rows stay in LDS: they are off the chain)
+                constexpr int NXI = decltype(nxc)::value, NUI = decltype(nuc)::value;
+                constexpr bool FIX = NXI > 0;
+                double g[FIX ? NXI : 1], ar[FIX ? NXI : 1], br[FIX ? NUI : 1];    // (the weights' rows stay in LDS: they are off the chain)
                 if constexpr (FIX) {
-                    const int tx = t < NXC ? t : 0;
+                    const int tx = t < NXI ? t : 0;
 #pragma unroll
-                    for (int a = 0; a < NXC; ++a) {
+                    for (int a = 0; a < NXI; ++a) {
                         g[a] = w.own ? lds[w.o.G + a * w.np + t] : 0.0;
-                        ar[a] = sh[p.so.At + tx * NXC + a];
+                        ar[a] = sh[p.so.At + tx * NXI + a];
                     }
 #pragma unroll
-                    for (int k = 0; k < NUC; ++k) br[k] = sh[p.so.Bt + tx * NUC + k];
+                    for (int k = 0; k < NUI; ++k) br[k] = sh[p.so.Bt + tx * NUI + k];
                 }
                 for (;;) {
                     double vu, xn = 0.0;
                     if constexpr (FIX) {
-                        double xv[NXC];
+                        double xv[NXI];
 #pragma unroll
-                        for (int a = 0; a < NXC; ++a) xv[a] = cur[a];
+                        for (int a = 0; a < NXI; ++a) xv[a] = cur[a];
                         vu = w.vr;
 #pragma unroll
-                        for (int a = 0; a < NXC; ++a) vu = __builtin_fma(g[a], xv[a], vu);
+                        for (int a = 0; a < NXI; ++a) vu = __builtin_fma(g[a], xv[a], vu);
                         vu = w.own ? vu : 0.0;
-                        if (t < NUC) uw[t] = vu + w.ctr;              // same wavefront as the readers below: LDS keeps the order
-                        if (t < NXC) {
+                        if (t < NUI) uw[t] = vu + w.ctr;              // same wavefront as the readers below: LDS keeps the order
+                        if (t < NXI) {
 #pragma unroll
-                            for (int a = 0; a < NXC; ++a) xn = __builtin_fma(ar[a], xv[a], xn);
+                            for (int a = 0; a < NXI; ++a) xn = __builtin_fma(ar[a], xv[a], xn);
 #pragma unroll
-                            for (int k = 0; k < NUC; ++k) xn = __builtin_fma(br[k], uw[k], xn);
+                            for (int k = 0; k < NUI; ++k) xn = __builtin_fma(br[k], uw[k], xn);
                             nxt[t] = xn;
                         }
                     } else {
@@ -980,8 +998,9 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
 bool launch_wg(const KParams &p, hipStream_t stream, const char **name)
 {
     const size_t bytes = wg_lds_bytes(p.nx, p.nu, p.N);
+    void (*kern)(KParams) = lqmpc_wg_kernel;
     // dynamic-LDS opt-in (per device and per function: set on every launch, it is a cheap host-side call)
-    const hipError_t e = hipFuncSetAttribute((const void *)lqmpc_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) {
         fprintf(stderr, "lqmpc: hipFuncSetAttribute(%zu bytes of LDS): %s\n", bytes, hipGetErrorString(e));
         return false;
@@ -990,7 +1009,7 @@ bool launch_wg(const KParams &p, hipStream_t stream, const char **name)
     long long z[16] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_prof), z, sizeof z);
 #endif
-    hipLaunchKernelGGL(lqmpc_wg_kernel, dim3((unsigned)p.Bsz), dim3(256), bytes, stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.Bsz), dim3(256), bytes, stream, p);
 #ifdef LQMPC_WG_PROF
     (void)hipStreamSynchronize(stream);
     (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_wg_prof), sizeof z);
