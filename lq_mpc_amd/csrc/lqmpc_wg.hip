@@ -35,7 +35,7 @@ namespace lqmpc {
 using namespace wg;
 
 #ifdef LQMPC_WG_PROF
-__device__ long long g_wg_prof[16];
+__device__ long long g_wg_prof[32];
 #define PROF(k) do { const long long now_ = clock64(); if (threadIdx.x == 0 && blockIdx.x == 0) g_wg_prof[k] += now_ - prof_t; prof_t = clock64(); } while (0)
 #define PROF_START long long prof_t = clock64()
 #else
@@ -68,7 +68,7 @@ __host__ __device__ inline WgOff wg_offsets(int nx, int nu, int N)
     o.act = c;  c += np;
     o.lam = c;  c += np;
     o.list = c; c += np / 2;
-    o.red = c;  c += 16;
+    o.red = c;  c += 24;
     o.xs = c;   c += 2 * nx + 8;
     o.AB = c;   c += nx * nx + nx * nu;
     o.shn = 3 * nx * nx + nu * nu + 2 * nu + (nx + nu) * N + nx * nu;     // everything of the shared block before x0s
@@ -98,35 +98,62 @@ bool wg_supported(const KParams &p, const double *lb, const double *ub)
 }
 
 // ---- workgroup reductions over the threads that own a row (others pass the neutral element) ----
+// Within a wavefront: four DPP row rotations give every lane its 16-lane row's result, four v_readlane pairs combine the rows (a
+// __shfl_xor butterfly is six trips through the LDS crossbar: 900 ticks per block_max against 550, tools/ubench/reduce_rate.hip).
+// Across the four wavefronts: one LDS slot per wave and ONE barrier; consecutive reductions alternate between two sets of slots, so a
+// fast wave's next write cannot overtake a slow wave's read of this one (any other barrier in between orders them as well).
+struct Red {
+    ldsd *p;                  // 24 doubles: [0..8) the two sets of wave slots, [8] the factorisation's flag, [12..14) rank counters (ints), [16..20) flag slots
+    int par;
+};
+__device__ __forceinline__ double row_ror(double x, int n)       // n in {1, 2, 4, 8}: rotate within each 16-lane row
+{
+    long long v = __double_as_longlong(x);
+    switch (n) {
+    case 1: v = __builtin_amdgcn_update_dpp(0ll, v, 0x121, 0xF, 0xF, true); break;
+    case 2: v = __builtin_amdgcn_update_dpp(0ll, v, 0x122, 0xF, 0xF, true); break;
+    case 4: v = __builtin_amdgcn_update_dpp(0ll, v, 0x124, 0xF, 0xF, true); break;
+    default: v = __builtin_amdgcn_update_dpp(0ll, v, 0x128, 0xF, 0xF, true); break;
+    }
+    return __longlong_as_double(v);
+}
 __device__ __forceinline__ double wave_sum(double x)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    return x;
+    x += row_ror(x, 8); x += row_ror(x, 4); x += row_ror(x, 2); x += row_ror(x, 1);
+    return (rdlane(x, 0) + rdlane(x, 16)) + (rdlane(x, 32) + rdlane(x, 48));
 }
 __device__ __forceinline__ double wave_max(double x)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o));
-    return x;
+    x = fmax(x, row_ror(x, 8)); x = fmax(x, row_ror(x, 4)); x = fmax(x, row_ror(x, 2)); x = fmax(x, row_ror(x, 1));
+    return fmax(fmax(rdlane(x, 0), rdlane(x, 16)), fmax(rdlane(x, 32), rdlane(x, 48)));
 }
-__device__ __forceinline__ double block_sum(double x, ldsd *red)
+__device__ __forceinline__ double block_sum(double x, Red &R)
 {
     x = wave_sum(x);
+    ldsd *s = R.p + 4 * R.par;
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = x;
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    R.par ^= 1;
+    return (s[0] + s[1]) + (s[2] + s[3]);
 }
-__device__ __forceinline__ double block_max(double x, ldsd *red)
+__device__ __forceinline__ double block_max(double x, Red &R)
 {
     x = wave_max(x);
+    ldsd *s = R.p + 4 * R.par;
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = x;
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
-    __syncthreads();
-    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    R.par ^= 1;
+    return fmax(fmax(s[0], s[1]), fmax(s[2], s[3]));
 }
-__device__ __forceinline__ bool block_any(bool f) { return __syncthreads_or(f ? 1 : 0) != 0; }
+__device__ __forceinline__ bool block_any(bool f, Red &R)        // (__syncthreads_or costs two barriers and an LDS reduction: 580 ticks against 300)
+{
+    const int w = __ballot(f) != 0ull;
+    ldsi *s = (ldsi *)(R.p + 16) + 4 * R.par;
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = w;
+    __syncthreads();
+    R.par ^= 1;
+    return (s[0] | s[1] | s[2] | s[3]) != 0;
+}
 
 // acc + sum_{y<len} a[y*sa] * b[y*sb] for short runtime lengths (nx, nu <= 16): loads issued eight / four at a
 // time so that their LDS latencies overlap instead of adding up
@@ -160,6 +187,7 @@ struct Wg {
     double preg[PREG];        // my share of P (flat index t + 256 m over the block image)
     double h, ctr, vr;        // half-width and centre of my row's input box (row < n; 1, 0 otherwise); v_r of my row
     bool own;                 // this thread owns row t (t < n)
+    Red R;                    // workgroup-reduction slots and their parity
     // solver state of my row
     double sl, su, zl, zu, rd, v, qs, act_prev;
 
@@ -277,11 +305,11 @@ struct Wg {
     {
         if (nx == 8 && nu == 4 && N == 30 && n == 120) {
             Wg c{p, wg_offsets(8, 4, 30), lds, 120, 8, 128, 8, 4, 30, t};
-            c.own = own; c.h = h; c.ctr = ctr; c.vr = 0.0;
+            c.own = own; c.h = h; c.ctr = ctr; c.vr = 0.0; c.R = R;
             c.setup_impl(b);
 #pragma unroll
             for (int m = 0; m < PREG; ++m) preg[m] = c.preg[m];
-            vr = c.vr;
+            vr = c.vr; R.par = c.R.par;
         } else {
             setup_impl(b);
         }
@@ -541,12 +569,12 @@ struct Wg {
         ldsd *gq = lds + o.vw;
         ref_linear_term(gq);
         double qr = (t < np) ? gq[t] : 0.0;
-        if (block_any(own && ctr != 0.0)) {
+        if (block_any(own && ctr != 0.0, R)) {
             if (t < np) gq[t] = own ? ctr : 0.0;
             __syncthreads();
             qr += symv_row(gq);                                      // K still holds P here
         }
-        const bool have_qr = block_any(own && qr != 0.0);
+        const bool have_qr = block_any(own && qr != 0.0, R);
         const bool qr_rides = have_qr && nx < BS;                    // as column nx of the block-row image of Fq
         if (qr_rides && t < np) X[(t / BS) * BLK + (t % BS) * LD + nx] = own ? qr : 0.0;
         PROF(4);
@@ -607,12 +635,14 @@ struct Wg {
     // ---- active-set iterations from the dual side (see the header): 0 converged, 1 hand over to the fallback ----
     __device__ __forceinline__ int pdas_dual(double vu, double &act, int maxit, int &nfact, double &vout)
     {
-        ldsd *S = lds + o.S, *T = lds + o.T, *rb = lds + o.vb, *lamv = lds + o.lam, *red = lds + o.red;
+        ldsd *S = lds + o.S, *T = lds + o.T, *rb = lds + o.vb, *lamv = lds + o.lam;
         ldsi *list = (ldsi *)(lds + o.list);
+        PROF_START;
         for (int it = 0; it < maxit; ++it) {
             int m;
             const bool a = own && act != 0.0;
             const int rk = rank_active(a, m);
+            PROF(16);
             if (m > o.smax * BS) return 1;
             double vi = vu, lmine = 0.0;
             if (m > 0) {
@@ -631,6 +661,7 @@ struct Wg {
                     S[e] = val;
                 }
                 __syncthreads();
+                PROF(17);
                 const ldsd *sol;
                 bool ok = true;
                 if (nbm == 1) {
@@ -644,17 +675,23 @@ struct Wg {
                 }
                 if (!ok) return 1;
                 nfact += 1;
+                PROF(18);
                 if (own) for (int k = 0; k < m; ++k) vi = __builtin_fma(-wsym(t, list[k]), sol[k], vi);
                 if (a) { lmine = sol[rk]; vi = act * h; }
+                PROF(19);
             }
-            const double gtol = 1e-10 * block_max(a ? fabs(lmine) : 0.0, red);
+            const double gtol = 1e-10 * block_max(a ? fabs(lmine) : 0.0, R);
             double na = act;
             if (own) {
                 if (!a) na = (vi < -h * (1.0 + 1e-12)) ? -1.0 : ((vi > h * (1.0 + 1e-12)) ? 1.0 : 0.0);
                 else na = (act < 0.0) ? ((lmine <= gtol) ? -1.0 : 0.0) : ((lmine >= -gtol) ? 1.0 : 0.0);
             }
-            const bool anybad = block_any(own && !(fabs(vi) < 1e300));
-            const bool anych = block_any(own && na != act);
+            const bool anybad = block_any(own && !(fabs(vi) < 1e300), R);
+            const bool anych = block_any(own && na != act, R);
+            PROF(20);
+#ifdef LQMPC_WG_PROF
+            if (threadIdx.x == 0 && blockIdx.x == 0) { g_wg_prof[21] += 1; g_wg_prof[22] += m; }
+#endif
             if (anybad) return 1;
             act = na;
             if (!anych) { vout = vi; return 0; }
@@ -688,8 +725,8 @@ struct Wg {
             }
             const bool bad = !ok || (own && !(fabs(vi) < 1e300));
             const bool changed = own && (na != act);
-            const bool anybad = block_any(bad);
-            const bool anych = block_any(changed);
+            const bool anybad = block_any(bad, R);
+            const bool anych = block_any(changed, R);
             if (anybad) return false;
             act = na;
             if (!anych) { vout = vi; return true; }
@@ -700,11 +737,11 @@ struct Wg {
     // ---- Mehrotra predictor-corrector from the current iterate until gap / residual <= eps_rel (fallback path) ----
     __device__ __forceinline__ int ipm_run(double scale, double hmin, double eps_rel, int &budget, int &iters)
     {
-        ldsd *vb = lds + o.vb, *red = lds + o.red;
+        ldsd *vb = lds + o.vb;
         const double inv2n = 1.0 / (2.0 * n), mu_tol = eps_rel * scale * hmin, rd_tol = eps_rel * scale;
         for (; budget > 0; --budget) {
-            const double mu = block_sum(own ? sl * zl + su * zu : 0.0, red) * inv2n;
-            const double rn = block_max(own ? fabs(rd) : 0.0, red);
+            const double mu = block_sum(own ? sl * zl + su * zu : 0.0, R) * inv2n;
+            const double rn = block_max(own ? fabs(rd) : 0.0, R);
             if (!(mu < 1e300) || !(rn < 1e300)) return 2;
             if (mu <= mu_tol && rn <= rd_tol) return 0;
             iters += 1;
@@ -714,11 +751,11 @@ struct Wg {
             if (t < np) vb[t] = own ? (-rd - zl + zu) : 0.0;
             solve_vb();
             const double dva = own ? vb[t] : 0.0;
-            double mp = block_max(own ? fmax(-dva * isl, dva * isu) : 0.0, red);
-            double md = block_max(own ? fmax(1.0 + dva * isl, 1.0 - dva * isu) : 0.0, red);
+            double mp = block_max(own ? fmax(-dva * isl, dva * isu) : 0.0, R);
+            double md = block_max(own ? fmax(1.0 + dva * isl, 1.0 - dva * isu) : 0.0, R);
             const double apa = mp > 1.0 ? 1.0 / mp : 1.0, ada = md > 1.0 ? 1.0 / md : 1.0;
             const double dzla = -zl * (1.0 + isl * dva), dzua = -zu * (1.0 - isu * dva);
-            const double mua = block_sum(own ? (sl + apa * dva) * (zl + ada * dzla) + (su - apa * dva) * (zu + ada * dzua) : 0.0, red) * inv2n;
+            const double mua = block_sum(own ? (sl + apa * dva) * (zl + ada * dzla) + (su - apa * dva) * (zu + ada * dzua) : 0.0, R) * inv2n;
             double sg = mua / mu; sg = sg * sg * sg;
             const double smu = sg * mu;
             const double rcl = smu - sl * zl - dva * dzla, rcu = smu - su * zu + dva * dzua;
@@ -727,7 +764,7 @@ struct Wg {
             solve_vb();
             const double dv = own ? vb[t] : 0.0;
             const double dzl = (rcl - zl * dv) * isl, dzu = (rcu + zu * dv) * isu;
-            mp = block_max(own ? fmax(fmax(-dv * isl, dv * isu), fmax(-dzl / zl, -dzu / zu)) : 0.0, red);
+            mp = block_max(own ? fmax(fmax(-dv * isl, dv * isu), fmax(-dzl / zl, -dzu / zu)) : 0.0, R);
             const double ap = mp > p.tau ? p.tau / mp : 1.0;     // one step length for primal and dual
             if (own) {
                 sl += ap * dv; su -= ap * dv; zl += ap * dzl; zu += ap * dzu;
@@ -740,14 +777,13 @@ struct Wg {
     // ---- one box QP at the state in LDS (o.xs); result in v (my row) ----
     __device__ __forceinline__ int solve_qp(int &iters)
     {
-        ldsd *red = lds + o.red;
         const double vu = vunc();
         v = vu;
-        if (!block_any(own && !(fabs(vu) <= h))) { act_prev = 0.0; return 0; }     // presolve: interior minimiser
-        if (block_any(own && !(fabs(vu) < 1e300))) { v = 0.0; act_prev = 0.0; return 2; }
+        if (!block_any(own && !(fabs(vu) <= h), R)) { act_prev = 0.0; return 0; }     // presolve: interior minimiser
+        if (block_any(own && !(fabs(vu) < 1e300), R)) { v = 0.0; act_prev = 0.0; return 2; }
         // warm start: the previous step's face shifted by one stage, else the rows where v_unc leaves the box
         double act;
-        const bool have_prev = block_any(own && act_prev != 0.0);
+        const bool have_prev = block_any(own && act_prev != 0.0, R);
         if (have_prev) {
             if (t < np) lds[o.act + t] = own ? act_prev : 0.0;
             __syncthreads();
@@ -767,9 +803,9 @@ struct Wg {
         load_K(false, 0.0);
         qs = -symv_row(lds + o.vw);                               // q = -P v_unc
         __syncthreads();
-        double scale = block_max(own ? fabs(qs) : 0.0, red);
+        double scale = block_max(own ? fabs(qs) : 0.0, R);
         scale = fmax(scale, 1e-100);
-        const double hmin = -block_max(own ? -h : -1e300, red);
+        const double hmin = -block_max(own ? -h : -1e300, R);
         const double z0 = p.z0_scale * scale;
         sl = h; su = h; zl = z0; zu = z0; rd = qs;
         int budget = p.max_iter, status = 1;
@@ -806,6 +842,7 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
     const int nx = p.nx, nu = p.nu, N = p.N, n = p.n;
     Wg w{p, wg_offsets(nx, nu, N), lds, n, (n + BS - 1) / BS, ((n + BS - 1) / BS) * BS, nx, nu, N, t};
     w.own = t < n;
+    w.R = Red{lds + w.o.red, 0};
     w.h = w.own ? 0.5 * (p.sh[p.so.ub + t % nu] - p.sh[p.so.lb + t % nu]) : 1.0;
     w.ctr = w.own ? 0.5 * (p.sh[p.so.ub + t % nu] + p.sh[p.so.lb + t % nu]) : 0.0;
     w.vr = 0.0;
@@ -856,7 +893,7 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
                     c = __builtin_fma(dk, r, c);
                 }
         }
-        return block_sum(c, lds + w.o.red);
+        return block_sum(c, w.R);
     };
     PROF_START;
     // one loop for the three entry points: a single QP (solve), K start states (max V_N), T closed-loop steps
@@ -930,7 +967,7 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
                         }
                     }
                     const bool out = w.own && !(fabs(vu) <= w.h);
-                    if (__syncthreads_or(out ? 1 : 0)) break;
+                    if (block_any(out, w.R)) break;
                     // inside the box: commit the step (costs, trajectories); the next round writes the half nobody reads any more
                     if (t < nx) {
                         cost = __builtin_fma(xn, ldot(sh + p.so.Q + t * nx, 1, nxt, 1, nx), cost);
@@ -983,7 +1020,7 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
         }
     }
     if (mode == MODE_ROLLOUT) {
-        cost = block_sum(cost, lds + w.o.red);
+        cost = block_sum(cost, w.R);
         if (t == 0) p.JT[b] = cost;
     } else if (mode == MODE_MAXVN) {
         if (t == 0) p.MV[b] = best;
@@ -1006,7 +1043,7 @@ bool launch_wg(const KParams &p, hipStream_t stream, const char **name)
         return false;
     }
 #ifdef LQMPC_WG_PROF
-    long long z[16] = {0};
+    long long z[32] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_prof), z, sizeof z);
 #endif
     hipLaunchKernelGGL(kern, dim3((unsigned)p.Bsz), dim3(256), bytes, stream, p);
@@ -1015,6 +1052,8 @@ bool launch_wg(const KParams &p, hipStream_t stream, const char **name)
     (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_wg_prof), sizeof z);
     fprintf(stderr, "wg prof (block 0 ticks): chains %lld Cq %lld H %lld Fq %lld qr %lld makeW %lld [chol %lld triinv %lld ztz %lld] G/vr %lld | solve_qp %lld value_fn %lld rollout %lld\n",
             z[0], z[1], z[2], z[3], z[4], z[5], z[8], z[9], z[10], z[6], z[11], z[12], z[13]);
+    fprintf(stderr, "wg prof dual iterations (block 0): %lld iterations, mean m %.1f; ticks per iteration: rank %lld gather %lld solve %lld update %lld checks %lld\n",
+            z[21], z[21] ? (double)z[22] / z[21] : 0.0, z[16] / (z[21] ? z[21] : 1), z[17] / (z[21] ? z[21] : 1), z[18] / (z[21] ? z[21] : 1), z[19] / (z[21] ? z[21] : 1), z[20] / (z[21] ? z[21] : 1));
 #endif
     if (name) *name = "lqmpc_wg_kernel";
     return true;
