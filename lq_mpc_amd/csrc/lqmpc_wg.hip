@@ -154,6 +154,16 @@ __device__ __forceinline__ bool block_any(bool f, Red &R)        // (__syncthrea
     R.par ^= 1;
     return (s[0] | s[1] | s[2] | s[3]) != 0;
 }
+// three predicates in one reduction: bit k of the result = any thread's f_k
+__device__ __forceinline__ int block_any3(bool f0, bool f1, bool f2, Red &R)
+{
+    const int w = (__ballot(f0) != 0ull ? 1 : 0) | (__ballot(f1) != 0ull ? 2 : 0) | (__ballot(f2) != 0ull ? 4 : 0);
+    ldsi *s = (ldsi *)(R.p + 16) + 4 * R.par;
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = w;
+    __syncthreads();
+    R.par ^= 1;
+    return s[0] | s[1] | s[2] | s[3];
+}
 
 // acc + sum_{y<len} a[y*sa] * b[y*sb] for short runtime lengths (nx, nu <= 16): loads issued eight / four at a
 // time so that their LDS latencies overlap instead of adding up
@@ -686,8 +696,8 @@ struct Wg {
                 if (!a) na = (vi < -h * (1.0 + 1e-12)) ? -1.0 : ((vi > h * (1.0 + 1e-12)) ? 1.0 : 0.0);
                 else na = (act < 0.0) ? ((lmine <= gtol) ? -1.0 : 0.0) : ((lmine >= -gtol) ? 1.0 : 0.0);
             }
-            const bool anybad = block_any(own && !(fabs(vi) < 1e300), R);
-            const bool anych = block_any(own && na != act, R);
+            const int chk = block_any3(own && !(fabs(vi) < 1e300), own && na != act, false, R);
+            const bool anybad = (chk & 1) != 0, anych = (chk & 2) != 0;
             PROF(20);
 #ifdef LQMPC_WG_PROF
             if (threadIdx.x == 0 && blockIdx.x == 0) { g_wg_prof[21] += 1; g_wg_prof[22] += m; }
@@ -725,8 +735,8 @@ struct Wg {
             }
             const bool bad = !ok || (own && !(fabs(vi) < 1e300));
             const bool changed = own && (na != act);
-            const bool anybad = block_any(bad, R);
-            const bool anych = block_any(changed, R);
+            const int chk = block_any3(bad, changed, false, R);
+            const bool anybad = (chk & 1) != 0, anych = (chk & 2) != 0;
             if (anybad) return false;
             act = na;
             if (!anych) { vout = vi; return true; }
@@ -779,11 +789,12 @@ struct Wg {
     {
         const double vu = vunc();
         v = vu;
-        if (!block_any(own && !(fabs(vu) <= h), R)) { act_prev = 0.0; return 0; }     // presolve: interior minimiser
-        if (block_any(own && !(fabs(vu) < 1e300), R)) { v = 0.0; act_prev = 0.0; return 2; }
+        const int chk = block_any3(own && !(fabs(vu) <= h), own && !(fabs(vu) < 1e300), own && act_prev != 0.0, R);
+        if (!(chk & 1)) { act_prev = 0.0; return 0; }             // presolve: interior minimiser
+        if (chk & 2) { v = 0.0; act_prev = 0.0; return 2; }
         // warm start: the previous step's face shifted by one stage, else the rows where v_unc leaves the box
         double act;
-        const bool have_prev = block_any(own && act_prev != 0.0, R);
+        const bool have_prev = (chk & 4) != 0;
         if (have_prev) {
             if (t < np) lds[o.act + t] = own ? act_prev : 0.0;
             __syncthreads();
