@@ -68,7 +68,7 @@ __host__ __device__ inline WgOff wg_offsets(int nx, int nu, int N)
     o.act = c;  c += np;
     o.lam = c;  c += np;
     o.list = c; c += np / 2;
-    o.red = c;  c += 24;
+    o.red = c;  c += 32;
     o.xs = c;   c += 2 * nx + 8;
     o.AB = c;   c += nx * nx + nx * nu;
     o.shn = 3 * nx * nx + nu * nu + 2 * nu + (nx + nu) * N + nx * nu;     // everything of the shared block before x0s
@@ -103,7 +103,7 @@ bool wg_supported(const KParams &p, const double *lb, const double *ub)
 // Across the four wavefronts: one LDS slot per wave and ONE barrier; consecutive reductions alternate between two sets of slots, so a
 // fast wave's next write cannot overtake a slow wave's read of this one (any other barrier in between orders them as well).
 struct Red {
-    ldsd *p;                  // 24 doubles: [0..8) the two sets of wave slots, [8] the factorisation's flag, [12..14) rank counters (ints), [16..20) flag slots
+    ldsd *p;                  // 32 doubles: [0..8) the two sets of wave slots, [8] the factorisation's flag, [12..14) rank counters (ints), [16..20) flag slots, [24..32) interior_steps
     int par;
 };
 __device__ __forceinline__ double row_ror(double x, int n)       // n in {1, 2, 4, 8}: rotate within each 16-lane row
@@ -187,6 +187,85 @@ __device__ __forceinline__ double ldot(const ldsd *a, int sa, const ldsd *b, int
     }
     for (; y < len; ++y) acc = __builtin_fma(a[y * sa], b[y * sb], acc);
     return acc;
+}
+
+// ---- several interior steps of a closed loop without a barrier (compile-time nx, nu; no trajectories) ----
+// While the unconstrained minimiser stays inside the box the closed loop is x+ = At x + Bt (G0 x + v_r0 + ctr0), G0 = the first nu rows
+// of G: nothing of it needs the workgroup.  Every wavefront keeps the state in scalar registers (v_readlane of its lanes 0..nx-1, which
+// all compute the plant update; lanes 0..nu-1 of every wave carry the first rows of G besides their own) and tests its own rows of
+// v_unc = G x + v_r against the box, up to K steps ahead; one reduction then finds the first step at which any row left the box, f.
+// f = K: all K steps are taken.  f < K: wave 0 repeats the first f steps from the chunk's start for the cost and the state (a step
+// costs a few hundred ticks against ~1200 for the one-barrier step of the general loop, so the repeat is cheap; the caller grows K
+// 1, 4, 16 while chunks succeed).  The state after f steps goes to xs (LDS); dc = the stage costs of those steps in the lanes that
+// carry the cost (thread i < nx: x_i (Q x)_i, thread k < nu: u_k (R u)_k, as in the general loop); returned as cost + those.
+struct InteriorArgs {
+    const ldsd *G, *At, *Bt, *Qm, *Rm;    // G: column-major n x nx with leading dimension np; the rest row-major
+    ldsd *xs, *red;
+    int np, par;
+};
+struct InteriorRes { int f, par; double dc; };
+template <int NX, int NU>
+__device__ __noinline__ InteriorRes interior_steps(InteriorArgs A, int K, bool own, double vr, double h, double ctr, double cost)
+{
+    static_assert((NU & (NU - 1)) == 0 && (NX & (NX - 1)) == 0 && NU <= 4, "lane & (N - 1) picks the row");
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const ldsd *Gp = uni(A.G), *Atp = uni(A.At), *Btp = uni(A.Bt), *Qp = uni(A.Qm), *Rp = uni(A.Rm);
+    ldsd *xsp = uni(A.xs), *red = uni(A.red);
+    const int np = uni(A.np);
+    int par = uni(A.par);
+    K = uni(K);
+    const int ju = lane & (NU - 1), jx = lane & (NX - 1);
+    double g[NX], gu[NX], ar[NX], br[NU], qr[NX], rr[NU];
+#pragma unroll
+    for (int a = 0; a < NX; ++a) {
+        g[a] = own ? Gp[a * np + t] : 0.0;
+        gu[a] = Gp[a * np + ju];
+        ar[a] = Atp[jx * NX + a];
+        qr[a] = Qp[jx * NX + a];
+    }
+#pragma unroll
+    for (int k = 0; k < NU; ++k) { br[k] = Btp[jx * NU + k]; rr[k] = Rp[ju * NU + k]; }
+    ldsd *tmp = red + 24;                                        // v_r and the centre of rows 0..nu-1 (wave 0's lanes) for everybody
+    if (t < NU) { tmp[t] = vr; tmp[4 + t] = ctr; }
+    __syncthreads();
+    const double vru = tmp[ju], ctru = tmp[4 + ju];
+    double xown = 0.0, dc = 0.0;
+    const double xstart = xsp[jx];                               // my component of the state (every 16-lane row holds the state twice)
+    // steps from the chunk's start; with test: stop at the first step at which a row of this wavefront leaves the box.
+    // The state never leaves the vector registers: component a comes to every dot product through DPP row_newbcast:a.
+    auto run = [&](int steps, bool test) -> int {
+        double xold = xstart;
+        dc = cost;                                               // (same order of additions as the general loop)
+        for (int k = 0; k < steps; ++k) {
+            double vu = vr, uu = vru, xn = 0.0;
+            static_for<0, NX>([&](auto ac) { constexpr int a = decltype(ac)::value; fmac_rowb_3y(vu, uu, xn, xold, g[a], gu[a], ar[a], a); });
+            if (test && __ballot(own && !(fabs(vu) <= h)) != 0ull) return k;
+            uu += ctru;
+            static_for<0, NU>([&](auto jc) { constexpr int j = decltype(jc)::value; fmac_rowb(xn, uu, br[j], j); });
+            double qx = 0.0, ru = 0.0;
+            static_for<0, NX>([&](auto ac) { constexpr int a = decltype(ac)::value; fmac_rowb(qx, xn, qr[a], a); });
+            static_for<0, NU>([&](auto jc) { constexpr int j = decltype(jc)::value; fmac_rowb(ru, uu, rr[j], j); });
+            dc = (t < NX) ? __builtin_fma(xn, qx, dc) : dc;
+            dc = (t < NU) ? __builtin_fma(uu, ru, dc) : dc;
+            xold = xn;
+            xown = xn;
+        }
+        return steps;
+    };
+    const int fw = run(K, true);
+    ldsi *sl = (ldsi *)(red + 16) + 4 * par;
+    if (lane == 0) sl[wave] = fw;
+    __syncthreads();
+    par ^= 1;
+    const int f = min(min(sl[0], sl[1]), min(sl[2], sl[3]));
+    if (f < K) {
+        dc = cost;
+        if (wave == 0 && f > 0) run(f, false);                   // uniform per wavefront
+    }
+    if (f > 0 && t < NX) xsp[t] = xown;
+    __syncthreads();
+    return InteriorRes{uni(f), par, dc};
 }
 
 struct Wg {
@@ -701,6 +780,7 @@ struct Wg {
             PROF(20);
 #ifdef LQMPC_WG_PROF
             if (threadIdx.x == 0 && blockIdx.x == 0) { g_wg_prof[21] += 1; g_wg_prof[22] += m; }
+            if (threadIdx.x == 0) atomicAdd((unsigned long long *)&g_wg_prof[24 + (m > 63 ? 7 : m / 8)], 1ull);      // all blocks: histogram of m
 #endif
             if (anybad) return 1;
             act = na;
@@ -926,6 +1006,8 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
         stage_cost(false);
         if (p.X && t < nx) p.X[((long long)t * (p.T + 1)) * Bsz + b] = xs[t];
     }
+    const bool chunked = mode == MODE_ROLLOUT && nx == 8 && nu == 4 && !p.X && !p.U;
+    int kchunk = 1;
     for (int step = 0; step < nsteps; ++step) {
         if (mode == MODE_ROLLOUT) {
             // Interior steps, one barrier each (most steps of most rollouts: 27 % of the C5 launch went into them when each took
@@ -933,6 +1015,23 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
             // unclipped minimiser into the other half of the state buffer while the box test is still in flight: the test's
             // workgroup-wide OR is the one barrier, and it also publishes the state.  A step that fails the test (or holds a
             // NaN) leaves everything as it was and takes the general path below.
+            if (chunked) {
+                // (no trajectories, C5's dimensions: barrier-free chunks of interior steps, see interior_steps)
+                const InteriorArgs ia{lds + w.o.G, sh + p.so.At, sh + p.so.Bt, sh + p.so.Q, sh + p.so.R, xs, lds + w.o.red, w.np, 0};
+                while (step < nsteps) {
+                    const int kreq = kchunk < nsteps - step ? kchunk : nsteps - step;
+                    InteriorArgs a2 = ia;
+                    a2.par = w.R.par;
+                    const InteriorRes r = interior_steps<8, 4>(a2, kreq, w.own, w.vr, w.h, w.ctr, cost);
+                    w.R.par = r.par;
+                    cost = r.dc;
+                    step += r.f;
+                    if (r.f > 0) w.act_prev = 0.0;
+                    if (r.f < kreq) { kchunk = 1; break; }            // step `step` leaves the box: the general path below
+                    kchunk = kchunk < 16 ? 4 * kchunk : 16;
+                }
+                if (step >= nsteps) break;
+            } else {
             ldsd *uw = lds + w.o.vw;
             ldsd *cur = xs, *nxt = xs + nx;                           // the state ping-pongs between the two halves: one barrier per step
             // (NXI, NUI) > 0: the dimensions at compile time (C5's) -- my row of G and of the plant stay in registers over the
@@ -1002,6 +1101,7 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
                 __syncthreads();
             }
             if (step >= nsteps) break;
+            }
         }
         if (mode == MODE_MAXVN) {
             __syncthreads();
@@ -1063,6 +1163,7 @@ bool launch_wg(const KParams &p, hipStream_t stream, const char **name)
     (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_wg_prof), sizeof z);
     fprintf(stderr, "wg prof (block 0 ticks): chains %lld Cq %lld H %lld Fq %lld qr %lld makeW %lld [chol %lld triinv %lld ztz %lld] G/vr %lld | solve_qp %lld value_fn %lld rollout %lld\n",
             z[0], z[1], z[2], z[3], z[4], z[5], z[8], z[9], z[10], z[6], z[11], z[12], z[13]);
+    fprintf(stderr, "wg prof dual iterations, all blocks, by m in [0,8) [8,16) ...: %lld %lld %lld %lld %lld %lld %lld %lld\n", z[24], z[25], z[26], z[27], z[28], z[29], z[30], z[31]);
     fprintf(stderr, "wg prof dual iterations (block 0): %lld iterations, mean m %.1f; ticks per iteration: rank %lld gather %lld solve %lld update %lld checks %lld\n",
             z[21], z[21] ? (double)z[22] / z[21] : 0.0, z[16] / (z[21] ? z[21] : 1), z[17] / (z[21] ? z[21] : 1), z[18] / (z[21] ? z[21] : 1), z[19] / (z[21] ? z[21] : 1), z[20] / (z[21] ? z[21] : 1));
 #endif

@@ -206,6 +206,19 @@ __device__ __forceinline__ void fmac_rowb_cols4(double &a0, double &a1, double &
     }
 }
 
+// a_j += (lane c's x, broadcast over the row) * y_j for three accumulators behind one s_nop: one state component into three dot products
+__device__ __forceinline__ void fmac_rowb_3y(double &a0, double &a1, double &a2, double x, double y0, double y1, double y2, int c)
+{
+    switch (c) {
+#define LQMPC_X(C) case C: asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %3, %4 row_newbcast:" #C " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %1, %3, %5 row_newbcast:" #C " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %2, %3, %6 row_newbcast:" #C " row_mask:0xf bank_mask:0xf" \
+                                        : "+v"(a0), "+v"(a1), "+v"(a2) : "v"(x), "v"(y0), "v"(y1), "v"(y2)); break;
+        LQMPC_ROWB_CASES(LQMPC_X)
+#undef LQMPC_X
+    }
+}
+
 // two wait states tied to x: a DPP read of x that follows in program order is safe even if x was written by
 // the inline asm right before (the compiler's hazard recogniser does not see those writes)
 __device__ __forceinline__ void dpp_settle(double &x) { asm volatile("s_nop 1" : "+v"(x)); }
