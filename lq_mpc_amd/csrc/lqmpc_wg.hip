@@ -279,6 +279,7 @@ struct Wg {
     Red R;                    // workgroup-reduction slots and their parity
     // solver state of my row
     double sl, su, zl, zu, rd, v, qs, act_prev;
+    int last_m;               // size of the active set the last QP ended with (uniform; 0: it was interior)
 
     __device__ __forceinline__ ldsi *flag() { return (ldsi *)(lds + o.red + 8); }
     __device__ __forceinline__ const ldsd *shd() const { return lds + o.SH; }      // the batch-shared block, staged in LDS
@@ -731,6 +732,7 @@ struct Wg {
             int m;
             const bool a = own && act != 0.0;
             const int rk = rank_active(a, m);
+            last_m = m;
             PROF(16);
             if (m > o.smax * BS) return 1;
             double vi = vu, lmine = 0.0;
@@ -740,6 +742,12 @@ struct Wg {
                 if (t >= m && t < mp) rb[t] = 0.0;
                 __syncthreads();
                 const int cnt = nbm * (nbm + 1) / 2 * BLK;
+                if (nbm == 1) {                                   // one block: thread t <-> element (t / 16, t % 16), no decoding
+                    const int ia = t / BS, ib = t % BS;
+                    double val = (ia == ib) ? 1.0 : 0.0;
+                    if (ia < m && ib < m) val = wsym(list[ia], list[ib]);
+                    S[ia * LD + ib] = val;
+                } else
                 for (int e = t; e < cnt; e += THREADS) {          // S = W_AA, identity outside
                     const int bidx = e / BLK, w = e - bidx * BLK, r = w / LD, c = w - r * LD;
                     int ab = 0;
@@ -755,7 +763,7 @@ struct Wg {
                 bool ok = true;
                 if (nbm == 1) {
                     if (t < 64) ok = small_spd_solve(S, T, rb, lamv, m);
-                    ok = __syncthreads_and(ok ? 1 : 0) != 0;
+                    ok = !block_any(!ok, R);
                     sol = lamv;
                 } else {
                     ok = chol_blocked(S, lds + o.Linv, nbm, flag());
@@ -870,6 +878,7 @@ struct Wg {
         const double vu = vunc();
         v = vu;
         const int chk = block_any3(own && !(fabs(vu) <= h), own && !(fabs(vu) < 1e300), own && act_prev != 0.0, R);
+        last_m = 0;
         if (!(chk & 1)) { act_prev = 0.0; return 0; }             // presolve: interior minimiser
         if (chk & 2) { v = 0.0; act_prev = 0.0; return 2; }
         // warm start: the previous step's face shifted by one stage, else the rows where v_unc leaves the box
@@ -916,6 +925,7 @@ struct Wg {
             if (budget <= 0) break;
         }
         make_W(true);
+        last_m = 1;                                               // (the fallback does not count: assume a constrained step follows)
         v = vsol;
         act_prev = (status == 2) ? 0.0 : act;
         return status;
@@ -937,7 +947,7 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
     w.h = w.own ? 0.5 * (p.sh[p.so.ub + t % nu] - p.sh[p.so.lb + t % nu]) : 1.0;
     w.ctr = w.own ? 0.5 * (p.sh[p.so.ub + t % nu] + p.sh[p.so.lb + t % nu]) : 0.0;
     w.vr = 0.0;
-    w.act_prev = 0.0; w.v = 0.0; w.qs = 0.0; w.sl = w.su = w.zl = w.zu = 1.0; w.rd = 0.0;
+    w.last_m = 0; w.act_prev = 0.0; w.v = 0.0; w.qs = 0.0; w.sl = w.su = w.zl = w.zu = 1.0; w.rd = 0.0;
     w.setup(b);
     const ldsd *sh = w.shd();
     ldsd *xs = lds + w.o.xs;
@@ -1015,7 +1025,10 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
             // unclipped minimiser into the other half of the state buffer while the box test is still in flight: the test's
             // workgroup-wide OR is the one barrier, and it also publishes the state.  A step that fails the test (or holds a
             // NaN) leaves everything as it was and takes the general path below.
-            if (chunked) {
+            if (chunked && w.last_m > 0) {
+                // the last step ended on a non-empty active set: its shift is the next step's guess and an interior step is unlikely --
+                // no speculative attempt (the general path's presolve still catches an interior minimiser)
+            } else if (chunked) {
                 // (no trajectories, C5's dimensions: barrier-free chunks of interior steps, see interior_steps)
                 const InteriorArgs ia{lds + w.o.G, sh + p.so.At, sh + p.so.Bt, sh + p.so.Q, sh + p.so.R, xs, lds + w.o.red, w.np, 0};
                 while (step < nsteps) {
