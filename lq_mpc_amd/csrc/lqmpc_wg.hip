@@ -677,9 +677,8 @@ struct Wg {
             const int lane = t & 63, col = lane & 15, r0 = lane >> 4;
             for (int ib = wave; ib < nb; ib += 4) {
                 d4_t c = {0.0, 0.0, 0.0, 0.0};
-                for (int jb = 0; jb < nb; ++jb)
-                    c = (jb <= ib) ? block_mm<false, true>(lds + o.K + blk_index(ib, jb) * BLK, X + jb * BLK, c, true)
-                                   : block_mm<true, true>(lds + o.K + blk_index(jb, ib) * BLK, X + jb * BLK, c, true);
+                c = block_sum<false, true>(0, ib + 1, [&](int jb) { return lds + o.K + blk_index(ib, jb) * BLK; }, [&](int jb) { return X + jb * BLK; }, c, true);
+                c = block_sum<true, true>(ib + 1, nb, [&](int jb) { return lds + o.K + blk_index(jb, ib) * BLK; }, [&](int jb) { return X + jb * BLK; }, c, true);
                 const double cv[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {

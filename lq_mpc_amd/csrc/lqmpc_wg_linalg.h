@@ -481,13 +481,18 @@ __device__ __noinline__ void tri_invert_blocked(ldsd *K, const ldsd *Linv, int n
 {
     K = uni(K); Linv = uni(Linv); nb = uni(nb);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform: loops and block addresses on the scalar unit
+    __syncthreads();
     for (int j = nb - 1; j >= 0; --j) {
-        __syncthreads();
-        for (int m = j + 1 + wave; m < nb; m += 4) {                 // X_m = L_mj * Z_jj, in place
-            ldsd *A = K + blk_index(m, j) * BLK;
-            d4_t c = {0.0, 0.0, 0.0, 0.0};
-            c = block_mm<false, true>(A, Linv + j * BLK, c, false);
-            tile_store(A, c);
+        // (no barrier here: the panel touches block column j only, which the stores of column j+1 just before do not)
+        {                                                            // X_m = L_mj * Z_jj, in place; at most two blocks per wave
+            const int m0 = j + 1 + wave, m1 = m0 + 4;
+            ldsd *A0 = K + blk_index(m0 < nb ? m0 : j, j) * BLK, *A1 = K + blk_index(m1 < nb ? m1 : j, j) * BLK;
+            BOps o0, o1;
+            if (m0 < nb) load_ops<false, true>(A0, Linv + j * BLK, o0);
+            if (m1 < nb) load_ops<false, true>(A1, Linv + j * BLK, o1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m0 < nb) tile_store(A0, mfma_ops(o0, d4_t{0.0, 0.0, 0.0, 0.0}, false));
+            if (m1 < nb) tile_store(A1, mfma_ops(o1, d4_t{0.0, 0.0, 0.0, 0.0}, false));
         }
         __syncthreads();
         auto zij = [&](int i) {
