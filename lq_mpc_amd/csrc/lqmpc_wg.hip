@@ -35,7 +35,7 @@ namespace lqmpc {
 using namespace wg;
 
 #ifdef LQMPC_WG_PROF
-__device__ long long g_wg_prof[32];
+__device__ long long g_wg_prof[48];
 #define PROF(k) do { const long long now_ = clock64(); if (threadIdx.x == 0 && blockIdx.x == 0) g_wg_prof[k] += now_ - prof_t; prof_t = clock64(); } while (0)
 #define PROF_START long long prof_t = clock64()
 #else
@@ -367,10 +367,11 @@ struct Wg {
     // rows of the block-row matrix Y (np x 16, block layout) <- W_T * (rows of Ma), W_T an nx x nx weight in LDS
     __device__ __forceinline__ void weight_rows(const ldsd *Ma, const ldsd *Wt, ldsd *Y)
     {
-        if (t < np) {
-            const ldsd *src = Ma + (t / BS) * BLK + (t % BS) * LD;
-            ldsd *dst = Y + (t / BS) * BLK + (t % BS) * LD;
-            for (int x = 0; x < nx; ++x) dst[x] = ldot(Wt + x * nx, 1, src, 1, nx);
+        const int r = t & (THREADS / 2 - 1), half = t / (THREADS / 2);      // two threads per row (np <= 128): even / odd columns
+        if (r < np) {
+            const ldsd *src = Ma + (r / BS) * BLK + (r % BS) * LD;
+            ldsd *dst = Y + (r / BS) * BLK + (r % BS) * LD;
+            for (int x = half; x < nx; x += 2) dst[x] = ldot(Wt + x * nx, 1, src, 1, nx);
         }
     }
 
@@ -472,7 +473,7 @@ struct Wg {
                 for (int jb = 0; jb <= ib; ++jb, ++cnt) {
                     if ((cnt & 3) != wave) continue;
                     d4_t c = {0.0, 0.0, 0.0, 0.0};
-                    c = block_xyt(Ma + ib * BLK, X + jb * BLK, c, false);
+                    c = block_xyt(Ma + ib * BLK, X + jb * BLK, c, false, (nx + 3) / 4);      // Ma, X: n x nx, columns nx .. 15 are zero
                     tile_store(lds + o.K + blk_index(ib, jb) * BLK, c);
                 }
         }
@@ -509,7 +510,7 @@ struct Wg {
                     if ((cnt & 3) != wave) continue;
                     ldsd *C = lds + o.K + blk_index(ib, jb) * BLK;
                     d4_t c = tile_load(C);
-                    c = block_xyt(Ma + ib * BLK, X + jb * BLK, c, false);
+                    c = block_xyt(Ma + ib * BLK, X + jb * BLK, c, false, (nx + 3) / 4);
                     c *= 2.0;
                     tile_store(C, c);
                 }
@@ -729,6 +730,9 @@ struct Wg {
         PROF_START;
         for (int it = 0; it < maxit; ++it) {
             int m;
+#ifdef LQMPC_WG_PROF
+            const long long it_t0 = clock64();
+#endif
             const bool a = own && act != 0.0;
             const int rk = rank_active(a, m);
             last_m = m;
@@ -787,7 +791,10 @@ struct Wg {
             PROF(20);
 #ifdef LQMPC_WG_PROF
             if (threadIdx.x == 0 && blockIdx.x == 0) { g_wg_prof[21] += 1; g_wg_prof[22] += m; }
-            if (threadIdx.x == 0) atomicAdd((unsigned long long *)&g_wg_prof[24 + (m > 63 ? 7 : m / 8)], 1ull);      // all blocks: histogram of m
+            if (threadIdx.x == 0) {                                  // all blocks: histogram of m and the ticks spent per bucket
+                atomicAdd((unsigned long long *)&g_wg_prof[24 + (m > 63 ? 7 : m / 8)], 1ull);
+                atomicAdd((unsigned long long *)&g_wg_prof[32 + (m > 63 ? 7 : m / 8)], (unsigned long long)(clock64() - it_t0));
+            }
 #endif
             if (anybad) return 1;
             act = na;
@@ -1166,7 +1173,7 @@ bool launch_wg(const KParams &p, hipStream_t stream, const char **name)
         return false;
     }
 #ifdef LQMPC_WG_PROF
-    long long z[32] = {0};
+    long long z[48] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_prof), z, sizeof z);
 #endif
     hipLaunchKernelGGL(kern, dim3((unsigned)p.Bsz), dim3(256), bytes, stream, p);
@@ -1176,6 +1183,8 @@ bool launch_wg(const KParams &p, hipStream_t stream, const char **name)
     fprintf(stderr, "wg prof (block 0 ticks): chains %lld Cq %lld H %lld Fq %lld qr %lld makeW %lld [chol %lld triinv %lld ztz %lld] G/vr %lld | solve_qp %lld value_fn %lld rollout %lld\n",
             z[0], z[1], z[2], z[3], z[4], z[5], z[8], z[9], z[10], z[6], z[11], z[12], z[13]);
     fprintf(stderr, "wg prof dual iterations, all blocks, by m in [0,8) [8,16) ...: %lld %lld %lld %lld %lld %lld %lld %lld\n", z[24], z[25], z[26], z[27], z[28], z[29], z[30], z[31]);
+    fprintf(stderr, "wg prof   mean ticks per iteration by the same buckets: %lld %lld %lld %lld %lld %lld %lld %lld\n", z[32] / (z[24] ? z[24] : 1), z[33] / (z[25] ? z[25] : 1),
+            z[34] / (z[26] ? z[26] : 1), z[35] / (z[27] ? z[27] : 1), z[36] / (z[28] ? z[28] : 1), z[37] / (z[29] ? z[29] : 1), z[38] / (z[30] ? z[30] : 1), z[39] / (z[31] ? z[31] : 1));
     fprintf(stderr, "wg prof dual iterations (block 0): %lld iterations, mean m %.1f; ticks per iteration: rank %lld gather %lld solve %lld update %lld checks %lld\n",
             z[21], z[21] ? (double)z[22] / z[21] : 0.0, z[16] / (z[21] ? z[21] : 1), z[17] / (z[21] ? z[21] : 1), z[18] / (z[21] ? z[21] : 1), z[19] / (z[21] ? z[21] : 1), z[20] / (z[21] ? z[21] : 1));
 #endif

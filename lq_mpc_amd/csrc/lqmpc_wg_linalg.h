@@ -47,21 +47,25 @@ template <class T> __device__ __forceinline__ T *uni(T *p) { return (T *)(size_t
 // D = C +- op(X) * op(Y)'  for 16x16 blocks X, Y in LDS (row stride LD), op = identity or transpose.
 // C/D in the MFMA tile layout (element r of the result: row lane/16 + 4r, column lane%16).  One wave.
 // Operand fetch of v_mfma_f64_16x16x4_f64: lane l supplies A[l%16][4t + l/16] and B'[l%16][4t + l/16].
+// kt: number of 4-wide slabs of the contraction index that are not all zero (kt < 4: the operands' columns 4 kt .. 15 are padding)
 template <bool XT, bool YT>
-__device__ __forceinline__ d4_t block_mm(const ldsd *X, const ldsd *Y, d4_t c, bool negate)
+__device__ __forceinline__ d4_t block_mm(const ldsd *X, const ldsd *Y, d4_t c, bool negate, int kt = 4)
 {
     const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
     double a[4], b[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        a[t] = XT ? X[(4 * t + kq) * LD + i] : X[i * LD + 4 * t + kq];
-        b[t] = YT ? Y[(4 * t + kq) * LD + i] : Y[i * LD + 4 * t + kq];
+        if (t < kt) {
+            a[t] = XT ? X[(4 * t + kq) * LD + i] : X[i * LD + 4 * t + kq];
+            b[t] = YT ? Y[(4 * t + kq) * LD + i] : Y[i * LD + 4 * t + kq];
+        }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) c = __builtin_amdgcn_mfma_f64_16x16x4f64(negate ? -a[t] : a[t], b[t], c, 0, 0, 0);
+    for (int t = 0; t < 4; ++t)
+        if (t < kt) c = __builtin_amdgcn_mfma_f64_16x16x4f64(negate ? -a[t] : a[t], b[t], c, 0, 0, 0);
     return c;
 }
-__device__ __forceinline__ d4_t block_xyt(const ldsd *X, const ldsd *Y, d4_t c, bool negate) { return block_mm<false, false>(X, Y, c, negate); }
+__device__ __forceinline__ d4_t block_xyt(const ldsd *X, const ldsd *Y, d4_t c, bool negate, int kt = 4) { return block_mm<false, false>(X, Y, c, negate, kt); }
 
 // The operands of one block product as the MFMA wants them (8 doubles per lane), so that a sum of products can fetch the next
 // pair of blocks while the matrix core works on the current one (one wavefront per SIMD here: nothing else hides the LDS trip).
