@@ -355,9 +355,15 @@ struct Wg {
     {
         PROF_START;
         if (reload) load_K(false, 0.0);
-        const bool ok = factor();
-        PROF(8);
-        tri_invert_blocked(lds + o.K, lds + o.Linv, nb);
+        bool ok;
+        if (o.Xf + (nb - 1) * BLK <= o.total) {                  // (uniform) room for one block per column behind the Fq image
+            ok = chol_inverse_blocked(lds + o.K, lds + o.Linv, nb, flag(), lds + o.Xf);
+            PROF(8);
+        } else {
+            ok = factor();
+            PROF(8);
+            tri_invert_blocked(lds + o.K, lds + o.Linv, nb);
+        }
         PROF(9);
         ztz_blocked(lds + o.K, nb);
         PROF(10);

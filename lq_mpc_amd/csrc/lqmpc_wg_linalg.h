@@ -427,6 +427,93 @@ __device__ __noinline__ bool chol_blocked(ldsd *K, ldsd *Linv, int nb, ldsi *fla
     return *flag != 0;
 }
 
+// chol_blocked() with the inverse of the factor riding along: on return K holds Z = L^-1 (strict lower blocks; the diagonal blocks
+// of Z are in Linv and are copied into K), ready for ztz_blocked().  Top-down by block rows,
+//     Z_ij = -Z_ii S_ij,   S_ij = sum_{m=j}^{i-1} L_im Z_mj   (Z_jj = L_jj^-1),
+// and the work is done by waves 1..3 in the time they would otherwise wait for wave 0's diagonal block (two thirds of the
+// factorisation: the trailing update of block column kb is short against the 16-pivot chain of block kb+1).  In the trailing phase of
+// block column kb a wave finishes row kb of Z (Z_kb,kb = L_kb,kb^-1 exists since the phase before) and forms the sums of row kb+1
+// (that row of L is complete after panel kb); the sums wait in Sc (one block per column) for the next phase because Z_kb+1,kb+1 is
+// being computed by wave 0 right now.  Block column j always belongs to wave 1 + j mod 3: a sum reads Z blocks of its own column
+// only, i.e. blocks the same wave wrote (the LDS executes a wavefront's accesses in order), and nobody else reads or writes the
+// blocks it overwrites (row kb left of the diagonal: dead once its sums exist), so the two barriers per block column of the
+// factorisation are all the synchronisation there is.  Sc: nb - 1 blocks of LDS scratch.
+__device__ __noinline__ bool chol_inverse_blocked(ldsd *K, ldsd *Linv, int nb, ldsi *flag, ldsd *Sc)
+{
+    K = uni(K); Linv = uni(Linv); nb = uni(nb); flag = uni(flag); Sc = uni(Sc);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) *flag = 1;
+    __syncthreads();
+    if (wave == 0) {
+        const bool ok = diag_factor_invert(K, Linv);
+        if (!ok && (threadIdx.x & 63) == 0) *flag = 0;
+    }
+    for (int kb = 0; kb < nb - 1; ++kb) {
+        __syncthreads();
+        for (int ib = kb + 1 + wave; ib < nb; ib += 4) {             // panel: X_ib = A_ib,kb * Linv_kk', in place
+            ldsd *A = K + blk_index(ib, kb) * BLK;
+            d4_t c = {0.0, 0.0, 0.0, 0.0};
+            c = block_xyt(A, Linv + kb * BLK, c, false);
+            tile_store(A, c);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            ldsd *C = K + blk_index(kb + 1, kb + 1) * BLK, *X = K + blk_index(kb + 1, kb) * BLK;
+            d4_t c = tile_load(C);
+            c = block_xyt(X, X, c, true);
+            tile_store(C, c);
+            const bool ok = diag_factor_invert(C, Linv + (kb + 1) * BLK);
+            if (!ok && (threadIdx.x & 63) == 0) *flag = 0;
+        } else {
+            // trailing update: A_ib,jb -= X_ib X_jb'   (kb < jb <= ib), the diagonal block kb+1 excepted (wave 0)
+            auto step = [&](int &ib, int &jb, int cnt) { for (int q = 0; q < cnt; ++q) if (++jb > ib) { ++ib; jb = kb + 1; } };
+            int ib = kb + 1, jb = kb + 1;
+            step(ib, jb, wave);
+            if (ib < nb) {
+                BOps cur, nxt;
+                load_ops<false, false>(K + blk_index(ib, kb) * BLK, K + blk_index(jb, kb) * BLK, cur);
+                d4_t cc = tile_load(K + blk_index(ib, jb) * BLK), cn;
+                while (ib < nb) {
+                    int ib2 = ib, jb2 = jb;
+                    step(ib2, jb2, 3);
+                    const int ibn = (ib2 < nb) ? ib2 : ib, jbn = (ib2 < nb) ? jb2 : jb;
+                    load_ops<false, false>(K + blk_index(ibn, kb) * BLK, K + blk_index(jbn, kb) * BLK, nxt);
+                    cn = tile_load(K + blk_index(ibn, jbn) * BLK);
+                    __builtin_amdgcn_sched_barrier(0);
+                    cc = mfma_ops(cur, cc, true);
+                    __builtin_amdgcn_sched_barrier(0);
+                    tile_store(K + blk_index(ib, jb) * BLK, cc);
+                    cur = nxt; cc = cn; ib = ib2; jb = jb2;
+                }
+            }
+            // the inverse: my block columns j = wave-1, wave+2, ... <= kb
+            for (int j = wave - 1; j <= kb; j += 3) {
+                if (j < kb) {                                        // finish row kb: Z_kb,j = -Z_kb,kb S_kb,j
+                    d4_t z = {0.0, 0.0, 0.0, 0.0};
+                    z = block_mm<false, true>(Linv + kb * BLK, Sc + j * BLK, z, true);
+                    tile_store(K + blk_index(kb, j) * BLK, z);
+                }
+                d4_t sacc = {0.0, 0.0, 0.0, 0.0};                     // S_kb+1,j = sum_{m=j}^{kb} L_kb+1,m Z_mj
+                sacc = block_sum<false, true>(j, kb + 1, [&](int m) { return K + blk_index(kb + 1, m) * BLK; },
+                                              [&](int m) { return (m == j) ? Linv + j * BLK : K + blk_index(m, j) * BLK; }, sacc, false);
+                tile_store(Sc + j * BLK, sacc);
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = wave; j < nb - 1; j += 4) {                         // the last row: Z_nb-1,j = -Z_nb-1,nb-1 S_nb-1,j
+        d4_t z = {0.0, 0.0, 0.0, 0.0};
+        z = block_mm<false, true>(Linv + (nb - 1) * BLK, Sc + j * BLK, z, true);
+        tile_store(K + blk_index(nb - 1, j) * BLK, z);
+    }
+    for (int e = threadIdx.x; e < nb * BLK; e += THREADS) {          // diagonal blocks of Z
+        const int j = e / BLK;
+        K[blk_index(j, j) * BLK + (e - j * BLK)] = Linv[e];
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
 // Solve (L L') x = b.  b: LDS vector of nb*16 doubles (in place).  tmp: LDS scratch of 16 doubles.
 __device__ __noinline__ void solve_blocked(const ldsd *K, const ldsd *Linv, int nb, ldsd *b)
 {

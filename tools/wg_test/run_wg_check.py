@@ -28,8 +28,8 @@ for nb, ninst, ms_ in ((1, 4, 16), (3, 4, 7), (8, 4, 11), (8, 2048, 5), (8, 2048
         X = rng.standard_normal((n, n + 5)); K = X @ X.T / n + np.eye(n); Ks.append(K); bs.append(rng.standard_normal(n))
     Kp = np.stack([pack(Ks[i % 4], nb) for i in range(ninst)]); bv = np.stack([bs[i % 4] for i in range(ninst)])
     Lo = np.zeros_like(Kp); Wo = np.zeros_like(Kp); xo = np.zeros_like(bv); so = np.zeros((ninst, BS)); ok = np.zeros(ninst, dtype=np.int32); ms = ctypes.c_float()
-    cyc = np.zeros(8, dtype=np.int64)
-    rc = L.run_test(P(Kp), P(bv), P(Lo), P(xo), P(Wo), P(so), nb, ms_, ninst, P(ok), ctypes.byref(ms), P(cyc))
+    cyc = np.zeros(12, dtype=np.int64); W2 = np.zeros_like(Kp)
+    rc = L.run_test(P(Kp), P(bv), P(Lo), P(xo), P(Wo), P(so), nb, ms_, ninst, P(ok), ctypes.byref(ms), P(cyc), P(W2))
     errL = errx = errW = errs = 0
     for i in range(min(ninst, 4)):
         Lg = np.tril(unpack(Lo[i], nb)); Lr = np.linalg.cholesky(Ks[i]); errL = max(errL, np.abs(Lg - Lr).max())
@@ -39,4 +39,5 @@ for nb, ninst, ms_ in ((1, 4, 16), (3, 4, 7), (8, 4, 11), (8, 2048, 5), (8, 2048
         Wfull = unpack(Wo[i], nb); d = max(np.abs(Wfull[k*BS:(k+1)*BS, k*BS:(k+1)*BS] - Wfull[k*BS:(k+1)*BS, k*BS:(k+1)*BS].T).max() for k in range(nb))
         errW = max(errW, d)
         errs = max(errs, np.abs(so[i, :ms_] - np.linalg.solve(Ks[i][:ms_, :ms_], bs[i][:ms_])).max())
-    print(f'nb={nb} n={n} inst={ninst} m={ms_}: rc={rc} ok={ok.min()} |L| {errL:.1e} |x| {errx:.1e} |W| {errW:.1e} |small| {errs:.1e}  {ms.value:.3f} ms; ticks small {cyc[0]} chol {cyc[1]} solve {cyc[2]} triinv {cyc[3]} ztz {cyc[4]} [entry {cyc[5]} sums {cyc[6]} store {cyc[7]}]')
+    errW2 = max(np.abs(np.tril(unpack(W2[i], nb)) - np.tril(np.linalg.inv(Ks[i]))).max() for i in range(min(ninst, 4)))
+    print(f'nb={nb} n={n} inst={ninst} m={ms_}: rc={rc} ok={ok.min()} |L| {errL:.1e} |x| {errx:.1e} |W| {errW:.1e} |small| {errs:.1e}  {ms.value:.3f} ms; ticks small {cyc[0]} chol {cyc[1]} solve {cyc[2]} triinv {cyc[3]} ztz {cyc[4]} [entry {cyc[5]} sums {cyc[6]} store {cyc[7]}]; fused chol+inverse {cyc[8]} |W2| {errW2:.1e}')
