@@ -434,7 +434,7 @@ __device__ __noinline__ bool chol_blocked(ldsd *K, ldsd *Linv, int nb, ldsi *fla
 // factorisation: the trailing update of block column kb is short against the 16-pivot chain of block kb+1).  In the trailing phase of
 // block column kb a wave finishes row kb of Z (Z_kb,kb = L_kb,kb^-1 exists since the phase before) and forms the sums of row kb+1
 // (that row of L is complete after panel kb); the sums wait in Sc (one block per column) for the next phase because Z_kb+1,kb+1 is
-// being computed by wave 0 right now.  Block column j always belongs to wave 1 + j mod 3: a sum reads Z blocks of its own column
+// being computed by wave 0 right now.  A block column always belongs to the same wave: a sum reads Z blocks of its own column
 // only, i.e. blocks the same wave wrote (the LDS executes a wavefront's accesses in order), and nobody else reads or writes the
 // blocks it overwrites (row kb left of the diagonal: dead once its sums exist), so the two barriers per block column of the
 // factorisation are all the synchronisation there is.  Sc: nb - 1 blocks of LDS scratch.
@@ -486,8 +486,11 @@ __device__ __noinline__ bool chol_inverse_blocked(ldsd *K, ldsd *Linv, int nb, l
                     cur = nxt; cc = cn; ib = ib2; jb = jb2;
                 }
             }
-            // the inverse: my block columns j = wave-1, wave+2, ... <= kb
-            for (int j = wave - 1; j <= kb; j += 3) {
+            // the inverse: my block columns j <= kb (columns go to the three waves in snake order 1 2 3 3 2 1 1 2 ...: the sums of
+            // column j have kb + 1 - j products, and the snake keeps the three loads within a product or two of each other)
+            for (int j = 0; j <= kb; ++j) {
+                const int r6 = j % 6;
+                if (1 + (r6 < 3 ? r6 : 5 - r6) != wave) continue;
                 if (j < kb) {                                        // finish row kb: Z_kb,j = -Z_kb,kb S_kb,j
                     d4_t z = {0.0, 0.0, 0.0, 0.0};
                     z = block_mm<false, true>(Linv + kb * BLK, Sc + j * BLK, z, true);
