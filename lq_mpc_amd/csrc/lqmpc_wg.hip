@@ -486,7 +486,12 @@ struct Wg {
         __syncthreads();
         PROF(1);
         // suffix sums along the stage diagonals, in place; R on the stage-diagonal blocks
-        for (int ch = t; ch < n * nu; ch += THREADS) {
+        // (a chain that starts in row i0 has (n - 1 - i0) / nu + 1 elements: odd rounds deal the chains in reverse, so that a thread
+        // gets a long and a short one)
+        for (int base = 0, rnd = 0; base < n * nu; base += THREADS, ++rnd) {
+            const int cnt = (n * nu - base < THREADS) ? n * nu - base : THREADS;
+            if (t >= cnt) continue;
+            const int ch = (rnd & 1) ? base + cnt - 1 - t : base + t;
             const int i0 = ch / nu, j0 = ch - i0 * nu;
             if (i0 < j0) continue;                                   // upper triangle of a stage block: mirrored below
             const double radd = (i0 < nu) ? sh[p.so.R + i0 * nu + j0] : 0.0;
@@ -499,6 +504,15 @@ struct Wg {
                 for (int k = 0; k < 8; ++k) { e[k] = kaddr(i0 + (s - k) * nu, j0 + (s - k) * nu); tmp[k] = *e[k]; }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { *e[k] = run + radd; run += tmp[k]; }
+            }
+            if (s >= 3) {
+                ldsd *e[4];
+                double tmp[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { e[k] = kaddr(i0 + (s - k) * nu, j0 + (s - k) * nu); tmp[k] = *e[k]; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { *e[k] = run + radd; run += tmp[k]; }
+                s -= 4;
             }
             for (; s >= 0; --s) {
                 ldsd *e = kaddr(i0 + s * nu, j0 + s * nu);
