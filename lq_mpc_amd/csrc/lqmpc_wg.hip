@@ -92,7 +92,7 @@ size_t wg_lds_bytes(int nx, int nu, int N) { return (size_t)wg_offsets(nx, nu, N
 bool wg_supported(const KParams &p, const double *lb, const double *ub)
 {
     (void)lb; (void)ub;
-    if (p.n <= 32 || p.n > 128 || p.nx > 16) return false;
+    if (p.n <= 32 || p.n > 128 || p.nx > 16 || p.nu > 64) return false;      // (nx, nu: the closed-loop update lives in one wavefront)
     const WgOff o = wg_offsets(p.nx, p.nu, p.N);
     return o.total <= LDS_DOUBLES && o.smax >= 1;
 }
@@ -1150,17 +1150,22 @@ __global__ void __launch_bounds__(256, 1) lqmpc_wg_kernel(KParams p)
         }
         const int st = w.solve_qp(iters);
         status = st > status ? st : status;
-        publish_v();
         if (mode == MODE_ROLLOUT) {
+            // u_0, the plant and the stage cost live in wave 0 (nx <= 16, nu <= 64): the LDS executes one wavefront's accesses in
+            // order, so between the barrier that retires the readers of the old state and the one that publishes the new state
+            // nothing else is needed (publish_v + the update cost four barriers)
+            __syncthreads();
+            ldsd *uw = lds + w.o.vw;
+            if (t < nu) uw[t] = fmin(fmax(w.v, -w.h), w.h) + w.ctr;
             double xn = 0.0;
-            if (t < nx) xn = ldot(sh + p.so.Bt + t * nu, 1, uu, 1, nu, ldot(sh + p.so.At + t * nx, 1, xs, 1, nx));
-            __syncthreads();
+            if (t < nx) xn = ldot(sh + p.so.Bt + t * nu, 1, uw, 1, nu, ldot(sh + p.so.At + t * nx, 1, xs, 1, nx));
             if (t < nx) xs[t] = xn;
-            __syncthreads();
             stage_cost(true);
-            if (p.X && t < nx) p.X[((long long)t * (p.T + 1) + step + 1) * Bsz + b] = xs[t];
+            if (p.X && t < nx) p.X[((long long)t * (p.T + 1) + step + 1) * Bsz + b] = xn;
             if (p.U && t < nu) p.U[((long long)t * p.T + step) * Bsz + b] = uu[t];
+            __syncthreads();
         } else {
+            publish_v();
             const double vn = value_fn(xs);
             best = (vn > best || vn != vn) ? vn : best;
             if (mode == MODE_SOLVE) {
