@@ -14,6 +14,8 @@ using wg::fmac_rowb;
 using wg::fmac_rowb_self;
 using wg::fmac_rowb4;
 using wg::fmac_rowb_self4;
+using wg::fmac_rowb_lanes4;
+using wg::fmac_rowb_lanes4x2;
 using wg::dpp_settle;
 
 #ifdef LQMPC_R16_PROF
@@ -658,11 +660,15 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
                                     for (int s = 0; s < RB; ++s) wv[kk][s] = Wp[vrow[s] ? widx(rw[s], trow[s], lk, tlk) : 0];
                                 });
-                                static_for<4>([&](auto kc) {
-                                    constexpr int kk = decltype(kc)::value;
+                                if constexpr (RB == 2) fmac_rowb_lanes4x2(tt[0], tt[1], rhs, wv[0][0], wv[0][1], wv[1][0], wv[1][1], wv[2][0], wv[2][1], wv[3][0], wv[3][1], 4 * kg);
+                                else if constexpr (RB == 1) fmac_rowb_lanes4(tt[0], rhs, wv[0][0], wv[1][0], wv[2][0], wv[3][0], 4 * kg);
+                                else {
+                                    static_for<4>([&](auto kc) {
+                                        constexpr int kk = decltype(kc)::value;
 #pragma unroll
-                                    for (int s = 0; s < RB; ++s) fmac_rowb(tt[s], rhs, wv[kk][s], 4 * kg + kk);
-                                });
+                                        for (int s = 0; s < RB; ++s) fmac_rowb(tt[s], rhs, wv[kk][s], 4 * kg + kk);
+                                    });
+                                }
                             }
                         });
                         // the multipliers decide in their own lanes which bounds stay: rows la_k whose multiplier keeps its sign
@@ -793,11 +799,15 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #pragma unroll
                                     for (int s = 0; s < RB; ++s) wv[kk][s] = Mx[vrow[s] ? midx(rw[s], trow[s], lk, tlk) : 0];
                                 });
-                                static_for<4>([&](auto kc) {
-                                    constexpr int kk = decltype(kc)::value;
+                                if constexpr (RB == 2) fmac_rowb_lanes4x2(tt[0], tt[1], rhs, wv[0][0], wv[0][1], wv[1][0], wv[1][1], wv[2][0], wv[2][1], wv[3][0], wv[3][1], 4 * kg);
+                                else if constexpr (RB == 1) fmac_rowb_lanes4(tt[0], rhs, wv[0][0], wv[1][0], wv[2][0], wv[3][0], 4 * kg);
+                                else {
+                                    static_for<4>([&](auto kc) {
+                                        constexpr int kk = decltype(kc)::value;
 #pragma unroll
-                                    for (int s = 0; s < RB; ++s) fmac_rowb(tt[s], rhs, wv[kk][s], 4 * kg + kk);
-                                });
+                                        for (int s = 0; s < RB; ++s) fmac_rowb(tt[s], rhs, wv[kk][s], 4 * kg + kk);
+                                    });
+                                }
                             }
                         });
                         __syncthreads();

@@ -223,6 +223,39 @@ __device__ __forceinline__ void fmac_rowb_3y(double &a0, double &a1, double &a2,
     }
 }
 
+// a_s += sum over four consecutive lanes c0 .. c0+3 of (lane's x, broadcast over the row) * y_k,s behind one s_nop: four columns of a
+// matrix-vector product whose vector sits one entry per lane (RB = 1 or 2 accumulators: the row slots of the 16-lane-row kernels)
+#define LQMPC_LANES4_CASES(X) X(0, 1, 2, 3) X(4, 5, 6, 7) X(8, 9, 10, 11) X(12, 13, 14, 15)
+__device__ __forceinline__ void fmac_rowb_lanes4(double &a0, double x, double y0, double y1, double y2, double y3, int c0)
+{
+    switch (c0) {
+#define LQMPC_X(C0, C1, C2, C3) case C0: asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:" #C0 " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %0, %1, %3 row_newbcast:" #C1 " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %0, %1, %4 row_newbcast:" #C2 " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %0, %1, %5 row_newbcast:" #C3 " row_mask:0xf bank_mask:0xf" \
+                                        : "+v"(a0) : "v"(x), "v"(y0), "v"(y1), "v"(y2), "v"(y3)); break;
+        LQMPC_LANES4_CASES(LQMPC_X)
+#undef LQMPC_X
+    }
+}
+__device__ __forceinline__ void fmac_rowb_lanes4x2(double &a0, double &a1, double x, double y00, double y01, double y10, double y11,
+                                                   double y20, double y21, double y30, double y31, int c0)
+{
+    switch (c0) {
+#define LQMPC_X(C0, C1, C2, C3) case C0: asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %2, %3 row_newbcast:" #C0 " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %1, %2, %4 row_newbcast:" #C0 " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %0, %2, %5 row_newbcast:" #C1 " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %1, %2, %6 row_newbcast:" #C1 " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %0, %2, %7 row_newbcast:" #C2 " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %1, %2, %8 row_newbcast:" #C2 " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %0, %2, %9 row_newbcast:" #C3 " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %1, %2, %10 row_newbcast:" #C3 " row_mask:0xf bank_mask:0xf" \
+                                        : "+v"(a0), "+v"(a1) : "v"(x), "v"(y00), "v"(y01), "v"(y10), "v"(y11), "v"(y20), "v"(y21), "v"(y30), "v"(y31)); break;
+        LQMPC_LANES4_CASES(LQMPC_X)
+#undef LQMPC_X
+    }
+}
+
 // two wait states tied to x: a DPP read of x that follows in program order is safe even if x was written by
 // the inline asm right before (the compiler's hazard recogniser does not see those writes)
 __device__ __forceinline__ void dpp_settle(double &x) { asm volatile("s_nop 1" : "+v"(x)); }
