@@ -333,64 +333,48 @@ __device__ __forceinline__ bool diag_factor_invert(ldsd *D, ldsd *Dinv)
 }
 
 // One wave: solve S x = r for an m x m SPD system, m <= 16, S in one block (row stride LD, rows/columns >= m
-// hold the identity), r and x in LDS (x may alias r).  T: a block of LDS scratch.  Returns false on a
-// non-positive pivot.  Row per lane; the forward substitution rides along with the factorisation, the
-// backward one uses the transpose of L fetched back from T.  Compiled for MB = 4, 8, 12, 16 pivots (the identity rows up to MB
-// factor to themselves), so that no update sits behind a branch on m; the chain is pipelined as in diag_factor_invert.
+// hold the identity), r and x in LDS (x may alias r).  T: unused (a block of LDS scratch of the Cholesky version).  Returns false
+// on a non-positive pivot.  Row per lane.  Compiled for MB = 4, 8, 12, 16 pivots (the identity rows up to MB eliminate to
+// themselves), so that no update sits behind a branch on m.
 template <int MB>
 __device__ __forceinline__ bool small_spd_solve_mb(const ldsd *S, ldsd *T, const ldsd *r, ldsd *x, int m)
 {
+    (void)T;
     const int lane = threadIdx.x & 63;
     const int i = lane & 15;
-    double row[MB], sinv[MB], lt[MB];
+    double row[MB];
 #pragma unroll
     for (int j = 0; j < MB; ++j) row[j] = S[i * LD + j];
-    double acc = r[i], ysol = 0.0;
+    double rhs = r[i];
+    // Gauss-Jordan on [S | r] without pivoting (S is SPD: the pivots are those of its Cholesky factorisation squared): after pivot k
+    // column k is e_k in every row, so the right-hand side ends up as the solution and there is no back substitution (the
+    // Cholesky route needed the factor transposed through LDS and a second 16-step chain).  Per pivot: broadcast, reciprocal with
+    // one Newton step, the per-lane multiplier g = 1/d - 1 in the pivot row and -s_ik/d elsewhere, then one DPP FMA per live column;
+    // the next pivot's column comes first and its reciprocal is under way while the rest is updated.
     double d = rowb(row[0], 0);
     bool ok = d > 0.0;
-    double y = __builtin_amdgcn_rsq(d);
+    double inv = frcp1(d);
     static_for<0, MB>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        const double e = __builtin_fma(-d * y, y, 1.0);
-        const double s = __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
-        sinv[k] = s;
-        row[k] *= s;
-        const double nl = -row[k];
+        const double g = (i == k) ? inv - 1.0 : -row[k] * inv;
         if constexpr (k + 1 < MB) {
-            fmac_rowb(row[k + 1], row[k], nl, k + 1);
+            fmac_rowb_self(row[k + 1], g, k);
             dpp_settle(row[k + 1]);
             d = rowb(row[k + 1], k + 1);
             ok = ok && (d > 0.0);
-            y = __builtin_amdgcn_rsq(d);
+            inv = frcp1(d);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const double yk = rowb(acc, k) * s;                      // forward substitution, column k
-        ysol = (i == k) ? yk : ysol;
-        acc = __builtin_fma(nl, yk, acc);
-        constexpr int G = (MB - k - 2 > 0) ? (MB - k - 2) / 4 : 0;
-        static_for<0, G>([&](auto gc) {
+        constexpr int NR = (MB - k - 2 > 0) ? MB - k - 2 : 0, G4 = NR / 4;
+        static_for<0, G4>([&](auto gc) {
             constexpr int c = k + 2 + 4 * decltype(gc)::value;
-            fmac_rowb_cols4(row[c], row[c + 1], row[c + 2], row[c + 3], row[k], nl, c);
+            fmac_rowb_self4(row[c], row[c + 1], row[c + 2], row[c + 3], g, k);
         });
-        static_for<k + 2 + 4 * G, MB>([&](auto cc) { constexpr int c = decltype(cc)::value; fmac_rowb(row[c], row[k], nl, c); });
+        static_for<k + 2 + 4 * G4, MB>([&](auto cc) { fmac_rowb_self(row[decltype(cc)::value], g, k); });
+        fmac_rowb_self(rhs, g, k);
         __builtin_amdgcn_sched_barrier(0);
     });
-    if (lane < BS) {
-#pragma unroll
-        for (int j = 0; j < MB; ++j) T[i * LD + j] = row[j];
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int k = 0; k < MB; ++k) lt[k] = T[k * LD + i];          // L[k][lane]
-    double xs = 0.0;
-    acc = ysol;
-    static_for<0, MB>([&](auto kc) {
-        constexpr int k = MB - 1 - decltype(kc)::value;
-        const double xk = rowb(acc, k) * sinv[k];
-        xs = (i == k) ? xk : xs;
-        acc = __builtin_fma(-lt[k], xk, acc);                    // lanes j < k: y_j - sum_{r > j} l_rj x_r
-    });
-    if (lane < BS) x[i] = (i < m) ? xs : 0.0;
+    if (lane < BS) x[i] = (i < m) ? rhs : 0.0;
     return ok;
 }
 __device__ __forceinline__ bool small_spd_solve(const ldsd *S, ldsd *T, const ldsd *r, ldsd *x, int m)
