@@ -14,6 +14,8 @@ using wg::fmac_rowb;
 using wg::fmac_rowb_self;
 using wg::fmac_rowb4;
 using wg::fmac_rowb_self4;
+using wg::fmac_rowb_self2;
+using wg::fmac_rowb_self3;
 using wg::fmac_rowb_lanes4;
 using wg::fmac_rowb_lanes4x2;
 using wg::dpp_settle;
@@ -109,6 +111,23 @@ __device__ __forceinline__ void ifmac_self4(double *acc, double y, int k)
     else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = __builtin_fma(wg::rdlane(acc[e], k), y, acc[e]);
+    }
+}
+// The tail of pivot K's own group of four columns (columns K+1 .. 4 (K/4) + 3) together with the right-hand side: one to four
+// self-updates behind a single s_nop instead of one each
+template <int LPI, int K, int CS>
+__device__ __forceinline__ void ifmac_self_tail(double (&S)[CS], double &rhs, double g)
+{
+    constexpr int r = K % 4;
+    if constexpr (LPI == 16) {
+        if constexpr (r == 0) fmac_rowb_self4(S[K + 1], S[K + 2], S[K + 3], rhs, g, K);
+        else if constexpr (r == 1) fmac_rowb_self3(S[K + 1], S[K + 2], rhs, g, K);
+        else if constexpr (r == 2) fmac_rowb_self2(S[K + 1], rhs, g, K);
+        else fmac_rowb_self(rhs, g, K);
+    } else {
+#pragma unroll
+        for (int j = K + 1; j < 4 * (K / 4) + 4; ++j) S[j] = __builtin_fma(wg::rdlane(S[j], K), g, S[j]);
+        rhs = __builtin_fma(wg::rdlane(rhs, K), g, rhs);
     }
 }
 template <int LPI>
@@ -631,17 +650,9 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                                 const double inv = frcp1(d);
                                 const double g = (i == k) ? (inv - 1.0) : -S[k] * inv;
 #pragma unroll
-                                for (int jg = 0; jg < CS / 4; ++jg) {
-                                    if (4 * jg + 3 > k && 4 * jg < cw) {
-                                        if (4 * jg > k) ifmac_self4<LPI>(&S[4 * jg], g, k);
-                                        else {
-#pragma unroll
-                                            for (int j = 4 * jg; j < 4 * jg + 4; ++j)
-                                                if (j > k) ifmac_self<LPI>(S[j], g, k);
-                                        }
-                                    }
-                                }
-                                ifmac_self<LPI>(rhs, g, k);
+                                for (int jg = 0; jg < CS / 4; ++jg)
+                                    if (4 * jg > k && 4 * jg < cw) ifmac_self4<LPI>(&S[4 * jg], g, k);
+                                ifmac_self_tail<LPI, k>(S, rhs, g);
                             }
                         });
                         const bool rowfail = iballot<LPI>(!ok, q) != 0;
@@ -770,17 +781,9 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                                 const double inv = frcp1(d);
                                 const double g = (i == k) ? (inv - 1.0) : -S[k] * inv;
 #pragma unroll
-                                for (int jg = 0; jg < CS / 4; ++jg) {
-                                    if (4 * jg + 3 > k && 4 * jg < cw) {
-                                        if (4 * jg > k) ifmac_self4<LPI>(&S[4 * jg], g, k);
-                                        else {
-#pragma unroll
-                                            for (int j = 4 * jg; j < 4 * jg + 4; ++j)
-                                                if (j > k) ifmac_self<LPI>(S[j], g, k);
-                                        }
-                                    }
-                                }
-                                ifmac_self<LPI>(rhs, g, k);
+                                for (int jg = 0; jg < CS / 4; ++jg)
+                                    if (4 * jg > k && 4 * jg < cw) ifmac_self4<LPI>(&S[4 * jg], g, k);
+                                ifmac_self_tail<LPI, k>(S, rhs, g);
                             }
                         });
                         const bool rowfail = iballot<LPI>(!ok, q) != 0;
@@ -900,17 +903,9 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                             const double inv = frcp1(d);
                             const double g = (i == k) ? (inv - 1.0) : -S[k] * inv;
 #pragma unroll
-                            for (int jg = 0; jg < CS / 4; ++jg) {
-                                if (4 * jg + 3 > k && 4 * jg < cw) {
-                                    if (4 * jg > k) ifmac_self4<LPI>(&S[4 * jg], g, k);
-                                    else {
-#pragma unroll
-                                        for (int j = 4 * jg; j < 4 * jg + 4; ++j)
-                                            if (j > k) ifmac_self<LPI>(S[j], g, k);
-                                    }
-                                }
-                            }
-                            ifmac_self<LPI>(rhs, g, k);
+                            for (int jg = 0; jg < CS / 4; ++jg)
+                                if (4 * jg > k && 4 * jg < cw) ifmac_self4<LPI>(&S[4 * jg], g, k);
+                            ifmac_self_tail<LPI, k>(S, rhs, g);
                         }
                     });
                     const bool rowfail = iballot<LPI>(!ok, q) != 0;
@@ -1029,17 +1024,9 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                         const double inv = frcp1(d);
                         const double g = (i == k) ? (inv - 1.0) : -S[k] * inv;
 #pragma unroll
-                        for (int jg = 0; jg < CS / 4; ++jg) {    // columns in groups of four: one uniform test per group
-                            if (4 * jg + 3 > k && 4 * jg < cw) {  // first half static, second uniform
-                                if (4 * jg > k) ifmac_self4<LPI>(&S[4 * jg], g, k);
-                                else {
-#pragma unroll
-                                    for (int j = 4 * jg; j < 4 * jg + 4; ++j)
-                                        if (j > k) ifmac_self<LPI>(S[j], g, k);
-                                }
-                            }
-                        }
-                        ifmac_self<LPI>(rhs, g, k);
+                        for (int jg = 0; jg < CS / 4; ++jg)      // columns in groups of four: one uniform test per group (first half static)
+                            if (4 * jg > k && 4 * jg < cw) ifmac_self4<LPI>(&S[4 * jg], g, k);
+                        ifmac_self_tail<LPI, k>(S, rhs, g);
                     }
                 });
                 const bool rowfail = iballot<LPI>(!ok, q) != 0;

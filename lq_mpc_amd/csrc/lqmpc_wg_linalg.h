@@ -256,6 +256,29 @@ __device__ __forceinline__ void fmac_rowb_lanes4x2(double &a0, double &a1, doubl
     }
 }
 
+// two / three self-updates (acc += lane c's acc * y) behind one s_nop: the tail of a pivot's own column group plus the right-hand side
+__device__ __forceinline__ void fmac_rowb_self2(double &a0, double &a1, double y, int c)
+{
+    switch (c) {
+#define LQMPC_X(C) case C: asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %2 row_newbcast:" #C " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %1, %1, %2 row_newbcast:" #C " row_mask:0xf bank_mask:0xf" \
+                                        : "+v"(a0), "+v"(a1) : "v"(y)); break;
+        LQMPC_ROWB_CASES(LQMPC_X)
+#undef LQMPC_X
+    }
+}
+__device__ __forceinline__ void fmac_rowb_self3(double &a0, double &a1, double &a2, double y, int c)
+{
+    switch (c) {
+#define LQMPC_X(C) case C: asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %3 row_newbcast:" #C " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %1, %1, %3 row_newbcast:" #C " row_mask:0xf bank_mask:0xf\n\t" \
+                                        "v_fmac_f64_dpp %2, %2, %3 row_newbcast:" #C " row_mask:0xf bank_mask:0xf" \
+                                        : "+v"(a0), "+v"(a1), "+v"(a2) : "v"(y)); break;
+        LQMPC_ROWB_CASES(LQMPC_X)
+#undef LQMPC_X
+    }
+}
+
 // two wait states tied to x: a DPP read of x that follows in program order is safe even if x was written by
 // the inline asm right before (the compiler's hazard recogniser does not see those writes)
 __device__ __forceinline__ void dpp_settle(double &x) { asm volatile("s_nop 1" : "+v"(x)); }
