@@ -429,6 +429,23 @@ def test_workgroup_kernel_dispatch_and_agreement(solver):
         solver.set_options(kernel=KERNEL_AUTO)
 
 
+@pytest.mark.parametrize("mix", ["default", "hard"])
+def test_workgroup_kernel_interior_chunks_agree_with_the_stepwise_loop(solver, mix, golden_dir):
+    """C5 rollouts without trajectories take the barrier-free chunks of interior steps (interior_steps<8,4>: state per wavefront,
+    first exit found by one reduction, wave 0 repeats a partial chunk); with trajectories the one-barrier step loop runs.  Same
+    closed loop, same order of additions: the costs agree to rounding, and both agree with the oracle."""
+    b = synth.make_batch(5, Bsz=96, fixture_dir=golden_dir, mix=mix)
+    T = 30 if mix == "default" else 12
+    chunked = solver.rollout_batch(T, *args(b), b["x0"], b["A_true"], b["B_true"])
+    assert solver.last_kernel() == "lqmpc_wg_kernel"
+    stepwise = solver.rollout_batch(T, *args(b), b["x0"], b["A_true"], b["B_true"], want_traj=True)
+    ref = orc.rollout_batch(T, *args(b), b["x0"], b["A_true"], b["B_true"])
+    assert np.all(chunked["status"] == 0) and np.all(stepwise["status"] == 0)
+    assert rel(chunked["J_T"], stepwise["J_T"]) < 1e-12
+    assert np.array_equal(chunked["iters"], stepwise["iters"])
+    assert rel(chunked["J_T"], ref["J_T"]) < TIGHT
+
+
 def test_16_lane_row_layout_whole_batch_tiered_and_hand_back(solver):
     """Rollouts of the shapes it serves run entirely in the 16-lane-row layout (lqmpc_r16_body.h; both of its builds,
     options.r16_build = 1/0); the packed family's tiered kernel uses it for its hardest instances (options.layout = 0 + nwide).  References, an off-centre box and
