@@ -368,6 +368,8 @@ static int prepare(lqmpc_handle *h, const Call &c, KParams &p)
     p.T = c.T; p.K = c.K; p.mode = c.mode;
     p.true_per_instance = c.true_per_instance;
     p.has_ref = (c.x_ref || c.u_ref) ? 1 : 0;
+    p.has_lin = p.has_ref;
+    for (int k = 0; k < nu; ++k) p.has_lin |= (c.ub[k] + c.lb[k] != 0.0) ? 1 : 0;
     p.max_iter = h->opt.max_iter; p.polish = h->opt.polish;
     p.presolve = h->opt.presolve < 0 ? 1 : h->opt.presolve;
     p.warm_start = h->opt.warm_start < 0 ? p.presolve : h->opt.warm_start;

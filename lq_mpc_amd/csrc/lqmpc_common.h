@@ -19,6 +19,7 @@ struct KParams {
     int T, K, mode;
     int true_per_instance;
     int has_ref;
+    int has_lin;                          // references or an off-centre box: the linear term has a constant part (host: has_ref || any lb + ub != 0)
     int max_iter, polish, presolve, warm_start;
     double eps, tau, z0_scale;
     long long Bsz;

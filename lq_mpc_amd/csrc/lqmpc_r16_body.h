@@ -397,9 +397,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         __builtin_amdgcn_sched_barrier(0);
         RPROF(3);
         // constant part of the linear term: qr = 2 gref + P centre (references / off-centre boxes only)
-        bool has_lin = p.has_ref != 0;
-#pragma unroll
-        for (int k = 0; k < NU; ++k) has_lin = has_lin || (sh[p.so.ub + k] + sh[p.so.lb + k] != 0.0);
+        const bool has_lin = p.has_lin != 0;         // (decided on the host: here it cost 2 NU dependent loads of the shared block per wavefront)
         double qr[RB];
 #pragma unroll
         for (int s = 0; s < RB; ++s) qr[s] = 0.0;
