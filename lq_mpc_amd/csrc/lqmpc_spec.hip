@@ -1131,6 +1131,23 @@ __global__ void __launch_bounds__(64, 1) lqmpc_spec_kernel(KParams p)
     spec_body<NX, NU, N, LPS, MODE>(p, lds, (long long)blockIdx.x * S::SPW, slot_end);
 }
 
+// The fallback pass over a device-side list for the one-instance-per-wavefront shapes: a bounded grid whose workgroups walk the list
+// (the plain kernel would start one workgroup per instance of the batch -- 262 144 at C4, 56 us of dispatch -- only for all of them to
+// read a count of zero and leave).
+template <int NX, int NU, int N, int LPS, int MODE>
+__global__ void __launch_bounds__(64, 1) lqmpc_spec_list_kernel(KParams p)
+{
+    using S = Spec<NX, NU, N, LPS>;
+    __shared__ double lds[S::LDS_DOUBLES];
+    const long long cnt = *p.count_dev;
+    const long long slot_end = cnt < p.Bsz ? cnt : p.Bsz;
+#pragma unroll 1
+    for (long long blk = blockIdx.x; blk * S::SPW < slot_end; blk += gridDim.x) {
+        spec_body<NX, NU, N, LPS, MODE>(p, lds, blk * S::SPW, slot_end);
+        __syncthreads();
+    }
+}
+
 // Two tiers in one launch (sorted rollouts).  The launch is as long as its slowest wavefront, and in the packed
 // layout that is the wavefront with the instances that stay constrained for all T steps: 16 instances, ~4000
 // instructions per active-set iteration, up to 78 iterations at C3.  So the p.nwide hardest instances, first
@@ -1301,6 +1318,18 @@ static void launch_one(const KParams &p, hipStream_t stream)
 {
     constexpr int SPW = 64 / LPS;
     const unsigned grid = (unsigned)((p.Bsz + SPW - 1) / SPW);
+    if constexpr (LPS == 64) {
+        if (p.count_dev && p.mode != MODE_PROBE) {
+            const unsigned gl = grid < 2048u ? grid : 2048u;
+            if (p.mode == MODE_SOLVE)
+                hipLaunchKernelGGL((lqmpc_spec_list_kernel<NX, NU, N, LPS, MODE_SOLVE>), dim3(gl), dim3(64), 0, stream, p);
+            else if (p.mode == MODE_MAXVN)
+                hipLaunchKernelGGL((lqmpc_spec_list_kernel<NX, NU, N, LPS, MODE_MAXVN>), dim3(gl), dim3(64), 0, stream, p);
+            else
+                hipLaunchKernelGGL((lqmpc_spec_list_kernel<NX, NU, N, LPS, MODE_ROLLOUT>), dim3(gl), dim3(64), 0, stream, p);
+            return;
+        }
+    }
     if (p.mode == MODE_SOLVE)
         hipLaunchKernelGGL((lqmpc_spec_kernel<NX, NU, N, LPS, MODE_SOLVE>), dim3(grid), dim3(64), 0, stream, p);
     else if (p.mode == MODE_MAXVN)

@@ -474,6 +474,30 @@ def test_16_lane_row_layout_whole_batch_tiered_and_hand_back(solver):
         solver.set_options(order=-1, layout=-1, r16_maxit=12, nwide=-1, r16_build=-1)
 
 
+@pytest.mark.parametrize("bsz", [96, 5000])
+def test_one_instance_per_wavefront_hand_back_walks_the_list(solver, bsz, golden_dir):
+    """C4's mapping (one instance per wavefront): with the iteration cap of the 16-lane-row family forced to 1 the constrained
+    instances are handed back, and the packed kernel's pass over the device-side list -- a bounded grid whose workgroups walk the
+    list (lqmpc_spec_list_kernel), 5000 instances here against its 2048 workgroups -- must restore every one; one-shot solves too."""
+    b = synth.make_batch(4, Bsz=bsz, fixture_dir=golden_dir, mix="hard")
+    T = 6
+    sub = np.arange(min(bsz, 256))
+    bs = dict(b, A=np.ascontiguousarray(b["A"][:, :, sub]), B=np.ascontiguousarray(b["B"][:, :, sub]))
+    ref = orc.rollout_batch(T, *args(bs), np.ascontiguousarray(b["x0"][:, sub]), b["A_true"], b["B_true"])
+    ref1 = orc.solve_batch(*args(bs), np.ascontiguousarray(b["x0"][:, sub]))
+    try:
+        full = solver.rollout_batch(T, *args(b), b["x0"], b["A_true"], b["B_true"])
+        assert "r64" in solver.last_kernel()
+        solver.set_options(r16_maxit=1)
+        g = solver.rollout_batch(T, *args(b), b["x0"], b["A_true"], b["B_true"])
+        g1 = solver.solve_batch(*args(b), b["x0"])
+    finally:
+        solver.set_options(r16_maxit=12)
+    assert np.all(g["status"] == 0) and np.all(g1["status"] == 0)
+    assert rel(g["J_T"][sub], ref["J_T"]) < TIGHT and rel(g["J_T"], full["J_T"]) < 1e-9
+    assert rel(g1["V_N"][sub], ref1["V_N"]) < TIGHT and u_err(g1["u_0"][:, sub], ref1["u_0"]) < RTOL
+
+
 def test_sweep_batch_is_max_vn_plus_rollout(solver):
     """lqmpc_sweep_batch = lqmpc_max_vn_batch + lqmpc_rollout_batch for the same models: fused in one launch on the
     16-lane-row layout (C3 and the reference's shapes), two launches elsewhere (C4 shape here), also after a forced hand-back."""
