@@ -68,6 +68,8 @@ struct lqmpc_handle {
     DevBuf key, perm, rec;           // difficulty ordering of rollout batches (its counters live in `fail`)
     DevBuf fail;                     // [count (2) | counters of the difficulty order | list] of the instances handed to the packed kernel
     bool fail_cleared = false;       // build_order zeroed count and counters in this call already
+    bool hist_ready = false;         // both sets of order counters are zero / being zeroed by the probe launches: no fill needed
+    int hist_turn = 0;               // which set the next probe counts into
     DevBuf st2, it2;                 // lqmpc_sweep_batch_dev without a fused kernel: status / iters of the max-V_N pass
     DevBuf stage[12];                // host-flavour staging (inputs and outputs)
     DevBuf arena;                    // host-flavour staging of small calls: one packed block, one copy each way
@@ -80,7 +82,8 @@ struct lqmpc_handle {
     bool use_wg = false;             // set by prepare(): this call runs on the workgroup kernel
 };
 
-constexpr size_t FAIL_HDR = 16 + (size_t)lqmpc::ORDER_CELLS * lqmpc::ORDER_PAD;    // ints in front of the hand-back list: its count, the order's counters
+constexpr size_t HIST_INTS = (size_t)lqmpc::ORDER_CELLS * lqmpc::ORDER_PAD;
+constexpr size_t FAIL_HDR = 16 + 2 * HIST_INTS;    // ints in front of the hand-back list: its count, the order's two alternating sets of counters
 
 static int ensure_host(HostBuf &b, size_t bytes)
 {
@@ -406,22 +409,35 @@ static int build_order(lqmpc_handle *h, KParams &p)
     if (B > (size_t)INT32_MAX) return fail(LQMPC_ERR_BAD_ARG, "ordering supports up to 2^31-1 instances");
     int rc = ensure(h, h->key, B * sizeof(double));
     if (!rc) rc = ensure(h, h->perm, B * sizeof(int));
+    const void *fail_before = h->fail.p;
     if (!rc) rc = ensure(h, h->fail, ((size_t)p.Bsz + FAIL_HDR) * sizeof(int));
     const size_t rec_doubles = (size_t)(p.nx * p.nx + p.nx * p.nu + p.nx);
     if (!rc) rc = ensure(h, h->rec, B * rec_doubles * sizeof(double));
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(h->fail.p, 0, FAIL_HDR * sizeof(int), h->stream));    // the hand-back count and the order's counters in one fill
+    // The hand-back count and the order's counters.  First call (or a new buffer): one fill of everything.  After that the probe
+    // launch itself zeroes the count and the set of counters the NEXT call will use (the sets alternate), so a call costs no fill
+    // launch (4 us of a 0.39 ms C3 call).  Any failure below leaves hist_ready false: the next call fills again.
+    if (h->fail.p != fail_before) h->hist_ready = false;
+    if (!h->hist_ready) {
+        HIP_TRY(hipMemsetAsync(h->fail.p, 0, FAIL_HDR * sizeof(int), h->stream));
+        h->hist_turn = 0;
+    }
+    h->hist_ready = false;
     h->fail_cleared = true;
     KParams q = p;
     q.mode = lqmpc::MODE_PROBE;
     q.perm = nullptr;
     q.key = (double *)h->key.p;
-    q.hist = (int *)h->fail.p + 16;
+    q.hist = (int *)h->fail.p + 16 + (size_t)h->hist_turn * HIST_INTS;
+    q.hist_next = (int *)h->fail.p + 16 + (size_t)(h->hist_turn ^ 1) * HIST_INTS;
+    q.fail_count = (int *)h->fail.p;
     q.stage = (double *)h->rec.p;
     const char *name = nullptr;
     if (!lqmpc::launch_spec(q, h->stream, &name)) return fail(LQMPC_ERR_UNSUPPORTED, "probe launch failed");
     lqmpc::launch_order_scatter(q, (int *)h->perm.p, h->stream);
     HIP_TRY(hipGetLastError());
+    h->hist_turn ^= 1;
+    h->hist_ready = true;
     p.perm = (const int *)h->perm.p;
     p.rec = (const double *)h->rec.p;
     return 0;

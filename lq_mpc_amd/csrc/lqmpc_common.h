@@ -32,7 +32,8 @@ struct KParams {
     int *status, *iters;                  // may be null
     const int *perm;                      // processing order (slot -> instance), null = natural order
     double *key;                          // MODE_PROBE output per instance: (difficulty bucket, position inside the bucket), two ints
-    int *hist;                            // MODE_PROBE: instances per difficulty bucket (ORDER_CELLS counters, zeroed by the host)
+    int *hist;                            // MODE_PROBE: instances per difficulty bucket (ORDER_CELLS counters, zero on entry)
+    int *hist_next;                       // MODE_PROBE: the counters of the NEXT call, zeroed by this launch (the two sets alternate: no fill launch per call)
     double *stage;                        // MODE_PROBE output: instance-major [A|B|x0] records (null: none)
     const double *rec;                    // input records staged by the probe (null: read A, B, x0 directly)
     long long nwide;                      // tiered rollout: the first nwide slots of the order get a wavefront each

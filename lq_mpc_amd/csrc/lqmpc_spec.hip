@@ -1179,6 +1179,13 @@ __global__ void __launch_bounds__(64) lqmpc_probe_kernel(KParams p)
 {
     const long long Bsz = p.Bsz;
     const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
+    // housekeeping that used to be a fill launch per call: the counters the NEXT call's probe will count into (the two sets
+    // alternate; the last reader of that set, the previous call's scatter, is long done) and this call's hand-back count
+    if (p.hist_next) {
+        const long long total = (long long)gridDim.x * 64;
+        for (long long e = b; e < (long long)ORDER_CELLS * ORDER_PAD; e += total) p.hist_next[e] = 0;
+    }
+    if (p.fail_count && b == 0) { p.fail_count[0] = 0; p.fail_count[1] = 0; }
     if (b >= Bsz) return;
     constexpr int REC = NX * NX + NX * NU + NX;
     const double *sh = p.sh;
