@@ -2,6 +2,7 @@
 // shared by the stand-alone kernel there and by the tiered launch in lqmpc_spec.hip.
 #pragma once
 #include "lqmpc_wg_linalg.h"
+#include "lqmpc_r16_setup.h"
 #include <cstdio>
 #include <utility>
 
@@ -55,7 +56,12 @@ struct R16 {
     static constexpr int oP = 0, oW = PK, oR = 2 * PK, oX = oR + VEC, oY = oX + VEC, oL = oY + VEC;
     static constexpr int oC = oL + CS / 2;            // Q | R | A | B | P_T: the open-loop value function's constants (read from LDS
     static constexpr int CN = 3 * NX * NX + NU * NU + NX * NU;   // when built for two waves per SIMD)
+#ifdef LQMPC_R16_GJ_SETUP
     static constexpr int SETUP = oW + 3 * n * NX + N * NX * NX;          // condensing tables alias the W region and what follows
+#else
+    static constexpr int SETUP = n * NX;                                 // the hand-over of G aliases the P / W regions (lqmpc_r16_setup.h)
+#endif
+    static constexpr int oG = 0;
     static constexpr int END = oC + CN + (CN & 1);
     static constexpr int oD = (END > SETUP) ? END : SETUP;        // a dummy slot BEHIND both: predicated LDS stores go there instead of toggling exec
     static constexpr int INST = oD + 2;
@@ -266,6 +272,94 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     long long prof_slowt = 0;
     long long prof_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+#ifndef LQMPC_R16_GJ_SETUP
+    {
+        // Set-up on the matrix core (lqmpc_r16_setup.h): Riccati recursion, W by rank-NU tile updates, G from the same sweep, P from
+        // its Toeplitz form -- v_mfma_f64_4x4x4_4b_f64 products only.  MFMA block g = (lane >> 2) & 3 works for the instance of lanes
+        // 16g .. 16g+15 (LPI = 16), so the set-up takes its inputs and its LDS by g and hands G back through LDS.
+        RPROF_START;
+        long long bg = b;
+        ldsd *Lg = L;
+        if constexpr (LPI == 16) {
+            const int gq = (lane >> 2) & 3;
+            const long long sraw = slot0 + gq, sl = sraw < slot_end ? sraw : slot_end - 1;
+            bg = p.perm ? (long long)p.perm[sl] : sl;
+            Lg = (ldsd *)lds_raw + gq * C::INST;
+        }
+        r16_setup_mfma<NX, NU, N, LPI, PACKED, RB>(p, bg, Lg, L, C::oP, C::oW, C::oG, C::oD, G);
+        RPROF(5);
+        // constant part of the unconstrained minimiser: v_r = -W (2 gref + P centre) = -2 W gref - centre (references / off-centre boxes only)
+        const bool has_lin = p.has_lin != 0;
+#pragma unroll
+        for (int s = 0; s < RB; ++s) vr[s] = 0.0;
+        if (has_lin) {
+            if (p.has_ref) {
+                //   d_r = -xref_r,  lam_r = Q_r d_r + A' lam_{r+1},  gref_r = B' lam_r - R uref_r   (columns r <-> x_{r+1}, u_r)
+                double qr[RB];
+#pragma unroll
+                for (int s = 0; s < RB; ++s) qr[s] = 0.0;
+                double lam[NX], A2[NX][NX], B2[NX][NU];
+#pragma unroll
+                for (int a = 0; a < NX; ++a) {
+                    lam[a] = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NX; ++c) A2[a][c] = p.rec ? p.rec[b * REC + a * NX + c] : p.A[(long long)(a * NX + c) * Bsz + b];
+#pragma unroll
+                    for (int k = 0; k < NU; ++k) B2[a][k] = p.rec ? p.rec[b * REC + NX * NX + a * NU + k] : p.B[(long long)(a * NU + k) * Bsz + b];
+                }
+#pragma unroll 1
+                for (int r = N - 1; r >= 0; --r) {
+                    const int oQ = (r < N - 1) ? p.so.Q : p.so.P;
+                    double l2[NX];
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int c = 0; c < NX; ++c) t = __builtin_fma(sh[oQ + a * NX + c], -sh[p.so.xref + c * N + r], t);
+#pragma unroll
+                        for (int c = 0; c < NX; ++c) t = __builtin_fma(A2[c][a], lam[c], t);
+                        l2[a] = t;
+                    }
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) lam[a] = l2[a];
+#pragma unroll
+                    for (int s = 0; s < RB; ++s) {
+                        const int ui = rw[s] % NU;
+                        double t = 0.0;
+#pragma unroll
+                        for (int k = 0; k < NU; ++k) {
+                            double tk = 0.0;
+#pragma unroll
+                            for (int a = 0; a < NX; ++a) tk = __builtin_fma(B2[a][k], lam[a], tk);
+#pragma unroll
+                            for (int j = 0; j < NU; ++j) tk = __builtin_fma(-sh[p.so.R + k * NU + j], sh[p.so.uref + j * N + r], tk);
+                            t = (ui == k) ? tk : t;
+                        }
+                        qr[s] = (vrow[s] && rw[s] / NU == r) ? 2.0 * t : qr[s];
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < RB; ++s) xL[rw[s]] = qr[s];
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < RB; ++s) {
+                    double t = 0.0;
+                    const int mr = vrow[s] ? rw[s] : 0, mt = vrow[s] ? tri[s] : 0;
+#pragma unroll
+                    for (int j = 0; j < n; ++j) t = __builtin_fma(Wp[ad(mr, mt, j)], xL[j], t);
+                    vr[s] = -t;
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int s = 0; s < RB; ++s) {
+                const int k = rw[s] % NU;
+                vr[s] = vrow[s] ? vr[s] - 0.5 * (sh[p.so.ub + k] + sh[p.so.lb + k]) : 0.0;
+            }
+        }
+        RPROF(6);
+    }
+#else
     {
         RPROF_START;
         ldsd *MA = Wp, *PM = MA + n * NX, *QM = PM + n * NX, *AP = QM + n * NX;
@@ -502,6 +596,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         __syncthreads();
         RPROF(6);
     }
+#endif
     RPROF_START;
     RPROF_ADD(13, clock64() - prof_t0);
 

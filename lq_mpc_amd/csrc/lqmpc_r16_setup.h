@@ -1,0 +1,300 @@
+// lqmpc_r16_setup.h -- the per-instance set-up of the 16-lane-row kernels on the fp64 matrix core:
+//   W = P^-1 (packed or full rows, LDS), P = 2 (Gamma'Qbar Gamma + Rbar) (LDS), G = -P^-1 Fq (registers, row layout)
+// for one model (A, B) and the batch-shared weights (utils_class.py:59-75 is the cost being condensed).
+//
+// Everything is a product of 4x4 matrices held one element per lane ("register matrix", zero-padded): v_mfma_f64_4x4x4_4b_f64
+// computes D = A_op B_op + C for four independent 4x4x4 blocks; block g lives in the lanes with (lane >> 2) & 3 == g, and
+// A_op[i][k] is taken from lane 16k + 4g + i, B_op[k][j] from lane 16k + 4g + j, D[i][j] lands in lane 16i + 4g + j (measured:
+// tools/ubench/mfma4_layout.hip).  So with the convention "entry [x][y] of block g in lane 16x + 4g + y" for a, b, c and the result:
+//     mm4(a, b, c) = a' b + c,
+// no LDS round trip, no barrier and no cross-lane instruction between dependent products.  With LPI = 16 the four blocks are the
+// four instances of the wavefront (block g = the instance whose rows live in lanes 16g .. 16g+15 everywhere else in the kernel: the
+// set-up addresses its inputs and its LDS by g, and hands its results over through LDS); with LPI = 64 (one instance per
+// wavefront) they are four different tiles of the one instance.  A 16-lane DPP row holds row x of all four blocks, so DPP row
+// broadcasts cannot serve here: the small inverse of Re is done with products as well (adjugate J Re J', det I = Re adj).
+//
+// Instead of condensing P and inverting it (Gauss-Jordan with a 20..40-pivot dependent chain: rounds 1-2), W comes from the
+// Riccati / innovations form of the same quadratic:  with Sg_N = P_T and, for j = N-1 .. 0,
+//     Re_j = R + B'Sg_{j+1}B,  K_j = Re_j^-1 B'Sg_{j+1}A,  Acl_j = A - B K_j,  Sg_j = Q + A'Sg_{j+1}Acl_j,
+// the change of variables w_j = u_j + K_j x_j decouples the cost:  U'HU = sum_j w_j'Re_j w_j,  U = T w with T unit lower block
+// triangular,  T_kj = -rho_k(j) B,  rho_k(j) = K_k Acl_{k-1} .. Acl_{j+1}  (k > j).  Hence
+//     W = (2H)^-1 = 1/2 T D^-1 T' = sum_j T(:, j) (Re_j^-1 / 2) T(:, j)'       (one rank-NU update per stage, on 4x4 tiles),
+//     G rows of stage k = -K_k Acl_{k-1} .. Acl_0 = -rho_k(-1)                    (what the rows rho_k have become after stage 0),
+// and the rows rho_k advance inside the same backward sweep (rho_k(j-1) = rho_k(j) Acl_j), so nothing is stored per stage.
+// P keeps its Lyapunov / Toeplitz form (round 2): block (bi, bj) = B' Lt_{bi+1} A^(bi-bj) B, Lt_N = P_T, Lt_k = Q + A'Lt_{k+1}A,
+// assembled tile by tile along the block diagonals so that the powers A^d B stream through one register.
+#pragma once
+#include "lqmpc_wg_linalg.h"
+#include <utility>
+
+namespace lqmpc {
+
+// (a)' b + c on register matrices (four independent blocks per wavefront)
+__device__ __forceinline__ double mm4(double a, double b, double c = 0.0) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+
+template <int I0, int I1, class F>
+__device__ __forceinline__ void sfor(F &&f)
+{
+    if constexpr (I0 < I1) { f(std::integral_constant<int, I0>{}); sfor<I0 + 1, I1>(f); }
+}
+
+template <int NX, int NU, int N, int LPI>
+struct SetupT {
+    static_assert(NX <= 4, "state matrices are one 4x4 tile");
+    static_assert(NU == 1 || NU == 2, "stage blocks of 1 or 2 rows (the small inverse of Re is written out for these)");
+    static constexpr int n = N * NU;
+    static constexpr int NT = (n + 3) / 4;                    // 4-row tiles of the n x n matrices
+    static constexpr int SPT = 4 / NU;                        // stages per tile
+    static constexpr int NTM = (LPI == 16) ? NT : (NT + 3) / 4;   // tile registers: LPI = 64 deals tile I to block I % 4, register I / 4
+    static constexpr int tile_of_stage(int j) { return (j * NU) / 4; }
+    static constexpr int off_of_stage(int j) { return (j * NU) % 4; }
+    // has tile I rows of a stage beyond j (i.e. is its rho non-zero when stage j is processed)?
+    static constexpr bool live(int I, int j) { return ((I + 1) * SPT < N ? (I + 1) * SPT : N) - 1 > j; }
+    static constexpr int GS = n * NX;                          // doubles of scratch for the hand-over of G
+};
+
+// Inverse of the leading NU x NU block of the register matrix Re (symmetric positive definite), zero elsewhere.  Not positive
+// definite: NaN (it spreads through every later product into G, and the solver hands the instance back).
+template <int NU>
+__device__ __forceinline__ double small_inverse(double Re, int r, int c)
+{
+    if constexpr (NU == 1) {
+        const double inv = (Re > 0.0) ? frcp(Re) : __builtin_nan("");
+        return (r == 0 && c == 0) ? inv : 0.0;
+    } else {
+        // adj(Re) = J Re J' with J = [0 1; -1 0];  Re adj(Re) = det I;  det into all four lanes of the 2 x 2 block by a product with ones
+        const double Jt = (r == 0 && c == 1) ? -1.0 : ((r == 1 && c == 0) ? 1.0 : 0.0);
+        const double ones = (r < 2 && c < 2) ? 1.0 : 0.0;
+        const double adj = mm4(mm4(Re, Jt), Jt);
+        const double det = mm4(ones, mm4(Re, adj));
+        const bool in = r < 2 && c < 2;
+        const double e00ok = (r == 0 && c == 0 && !(Re > 0.0)) ? __builtin_nan("") : 1.0;
+        const double idet = (in && !(det > 0.0)) ? __builtin_nan("") : frcp(in ? det : 1.0);
+        return in ? adj * idet * e00ok : 0.0;
+    }
+}
+
+// The set-up.  Lg: LDS of block g's instance (LPI = 16) or of the one instance (LPI = 64); oP / oW: where P and W go in it (packed
+// lower triangle: index row (row + 1) / 2 + col; or full rows of stride n + 1, both triangles); oG: n NX doubles of scratch for G
+// (may alias P / W: they are written after G has been read back); oD: a dummy slot for predicated stores.
+// bg: the instance block g works on.  Lq / valid rows: where the lane's OWN instance (q = lane / LPI) reads its rows of G back.
+// On return: P, W in LDS (a barrier has been passed), G[s][a] = row (i + LPI s) of G in registers.
+template <int NX, int NU, int N, int LPI, bool PACKED, int RB>
+__device__ __forceinline__ void r16_setup_mfma(const KParams &p, long long bg, wg::ldsd *Lg, wg::ldsd *Lq, int oP, int oW, int oG, int oD,
+                                              double (&G)[RB][NX])
+{
+    using T = SetupT<NX, NU, N, LPI>;
+    constexpr int n = T::n, NT = T::NT, SPT = T::SPT, NTM = T::NTM, LDW = n + 1;
+    constexpr int REC = NX * NX + NX * NU + NX;
+    const int lane = threadIdx.x, r = lane >> 4, c = lane & 3, g = (lane >> 2) & 3;
+    const long long Bsz = p.Bsz;
+    const double *sh = p.sh;
+    wg::ldsd *Pp = Lg + oP, *Wp = Lg + oW, *Gs = Lg + oG;
+    const int dP = oD - oP, dW = oD - oW, dG = oD - oG;
+    // ---- the model and the weights as register matrices ----
+    auto ldA = [&](int a, int k) -> double {
+        const bool v = a < NX && k < NX;
+        const int aa = v ? a : 0, kk = v ? k : 0;
+        const double x = p.rec ? p.rec[bg * REC + aa * NX + kk] : p.A[(long long)(aa * NX + kk) * Bsz + bg];
+        return v ? x : 0.0;
+    };
+    auto ldB = [&](int a, int k) -> double {
+        const bool v = a < NX && k >= 0 && k < NU;
+        const int aa = v ? a : 0, kk = v ? k : 0;
+        const double x = p.rec ? p.rec[bg * REC + NX * NX + aa * NU + kk] : p.B[(long long)(aa * NU + kk) * Bsz + bg];
+        return v ? x : 0.0;
+    };
+    auto ldS = [&](int o, int a, int k, int dim) -> double {
+        const bool v = a < dim && k < dim;
+        const double x = sh[o + (v ? a * dim + k : 0)];
+        return v ? x : 0.0;
+    };
+    const double A = ldA(r, c), At = ldA(c, r), Bp = ldB(r, c), Bt = ldB(c, r);
+    const double Q = ldS(p.so.Q, r, c, NX), PT = ldS(p.so.P, r, c, NX), Rp = ldS(p.so.R, r, c, NU);
+    const double nBp = -Bp, nBt = -Bt;
+
+    // ---- backward sweep: Riccati recursion, the rows rho_k, W by rank-NU updates ----
+    double Wacc[NTM][NT];                         // tile (I, J), J <= I: LPI = 16: Wacc[I][J]; LPI = 64: block g of Wacc[m][J] holds tile (4m+g, J)
+    double rho[NTM];                              // rho' of the rows of tile I (NX x 4: column = row of the tile)
+    double rho_r[(LPI == 64) ? NT : 1];           // LPI = 64: every tile's rho' in every block (the B operand of an update is one tile for all)
+#pragma unroll
+    for (int m = 0; m < NTM; ++m) {
+        rho[m] = 0.0;
+#pragma unroll
+        for (int J = 0; J < NT; ++J) Wacc[m][J] = 0.0;
+    }
+    if constexpr (LPI == 64) {
+#pragma unroll
+        for (int J = 0; J < NT; ++J) rho_r[J] = 0.0;
+    }
+    double S = PT;
+    sfor<0, N>([&](auto jc) {
+        constexpr int j = N - 1 - decltype(jc)::value;
+        constexpr int Ij = T::tile_of_stage(j), off = T::off_of_stage(j);
+        const double SA = mm4(S, A), SB = mm4(S, Bp);
+        const double F = mm4(Bp, SA), Re = mm4(Bp, SB, Rp);
+        const double R0 = small_inverse<NU>(Re, r, c);
+        const double K = mm4(R0, F);
+        const double Acl = mm4(nBt, K, A);
+        if constexpr (j > 0) {
+            const double Z = mm4(S, Acl);
+            S = mm4(A, Z, Q);
+        }
+        const double SH = (r < NU && c == off + r) ? 1.0 : 0.0;       // the identity block of T(:, j) at the tile position of stage j; as a right factor: moves columns 0.. to off..
+        const double R0h = 0.5 * R0;
+        const double nBRt = mm4(nBt, R0h);                            // -(1/2) B Re^-1
+        const double Ktp = mm4(K, SH);                                // K' in the columns of stage j
+        const double R1h = (off == 0) ? R0h : mm4(R0h, SH);           // Re^-1 / 2 in the columns of stage j
+        // T(:, j)' and (T(:, j) Re^-1 / 2)' on the rows of every tile from I_j on (rows of these register matrices: the NU columns of block j)
+        double Tt[NT], TDt[NTM];
+        sfor<Ij, NT>([&](auto Jc) {
+            constexpr int J = decltype(Jc)::value;
+            if constexpr (T::live(J, j)) {
+                if constexpr (LPI == 64) Tt[J] = mm4(nBp, rho_r[J < NT && LPI == 64 ? J : 0], J == Ij ? SH : 0.0);
+                else Tt[J] = mm4(nBp, rho[LPI == 16 ? J : 0], J == Ij ? SH : 0.0);
+            } else Tt[J] = SH;                                        // (J == Ij and no row of a later stage in the tile yet)
+        });
+        if constexpr (LPI == 16) {
+            sfor<Ij, NT>([&](auto Ic) {
+                constexpr int I = decltype(Ic)::value;
+                if constexpr (T::live(I, j)) TDt[I] = mm4(nBRt, rho[I], I == Ij ? R1h : 0.0);
+                else TDt[I] = R1h;
+            });
+            sfor<Ij, NT>([&](auto Ic) {
+                constexpr int I = decltype(Ic)::value;
+                sfor<Ij, I + 1>([&](auto Jc) {
+                    constexpr int J = decltype(Jc)::value;
+                    Wacc[I][J] = mm4(TDt[I], Tt[J], Wacc[I][J]);
+                });
+            });
+            sfor<Ij, NT>([&](auto Ic) {
+                constexpr int I = decltype(Ic)::value;
+                if constexpr (T::live(I, j)) rho[I] = mm4(Acl, rho[I], I == Ij ? Ktp : 0.0);
+                else rho[I] = Ktp;
+            });
+        } else {
+            constexpr int m0 = Ij / 4;
+            sfor<m0, NTM>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                const bool mine = (4 * m + g == Ij);
+                TDt[m] = mm4(nBRt, rho[m], mine ? R1h : 0.0);
+            });
+            sfor<Ij, NT>([&](auto Jc) {
+                constexpr int J = decltype(Jc)::value;
+                sfor<J / 4, NTM>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    Wacc[m][J] = mm4(TDt[m], Tt[J], Wacc[m][J]);      // (blocks whose tile 4m+g < J compute an upper-triangle tile: never stored)
+                });
+            });
+            sfor<m0, NTM>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                const bool mine = (4 * m + g == Ij);
+                rho[m] = mm4(Acl, rho[m], mine ? Ktp : 0.0);
+            });
+            sfor<Ij, NT>([&](auto Jc) {
+                constexpr int J = decltype(Jc)::value;
+                if constexpr (T::live(J, j)) rho_r[J] = mm4(Acl, rho_r[J], J == Ij ? Ktp : 0.0);
+                else rho_r[J] = Ktp;
+            });
+        }
+    });
+
+    // ---- G: rho' (NX x 4 per tile: lane (r, c) holds rho[row 4I + c][state r]) -> rows, through LDS ----
+#pragma unroll
+    for (int m = 0; m < NTM; ++m) {
+        const int I = (LPI == 16) ? m : 4 * m + g;
+        const int row = 4 * I + c;
+        Gs[(r < NX && row < n) ? row * NX + r : dG] = -rho[m];
+    }
+    __syncthreads();
+    {
+        const int i = lane % LPI;
+        const wg::ldsd *Gq = Lq + oG;
+#pragma unroll
+        for (int s = 0; s < RB; ++s) {
+            const int row = i + LPI * s;
+#pragma unroll
+            for (int a = 0; a < NX; ++a) {
+                const double x = Gq[row < n ? row * NX + a : 0];
+                G[s][a] = row < n ? x : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- W to LDS ----
+    auto store_tile = [&](wg::ldsd *M, int dummy, int I, int J, double val, bool on) {
+        const int row = 4 * I + r, col = 4 * J + c;
+        const bool low = on && row < n && col <= row;
+        if constexpr (PACKED) M[low ? row * (row + 1) / 2 + col : dummy] = val;
+        else {
+            M[low ? row * LDW + col : dummy] = val;
+            M[(low && col < row) ? col * LDW + row : dummy] = val;
+        }
+    };
+#pragma unroll
+    for (int m = 0; m < NTM; ++m)
+#pragma unroll
+        for (int J = 0; J < NT; ++J) {
+            const int I = (LPI == 16) ? m : 4 * m + g;
+            if ((LPI == 16) ? (J <= m) : (J <= 4 * m + 3)) store_tile(Wp, dW, I, J, Wacc[m][J], I < NT && J <= I);
+        }
+
+    // ---- P = 2 (H + Rbar): tile (I, I - D) = sum_p (Lt_{k+1} B placed at stage k's columns)' [A^(D SPT + p) B | A^(D SPT + p - 1) B | ..],  k = I SPT + p ----
+    {
+        double ap[NTM][SPT];                                          // a-operands of my tiles' stages
+        double Bpl[SPT];                                              // B in column block q of a tile
+#pragma unroll
+        for (int qq = 0; qq < SPT; ++qq) Bpl[qq] = ldB(r, c - qq * NU);
+#pragma unroll
+        for (int m = 0; m < NTM; ++m)
+#pragma unroll
+            for (int pp = 0; pp < SPT; ++pp) ap[m][pp] = 0.0;
+        double Lt = PT;
+        sfor<0, N>([&](auto kc) {
+            constexpr int k = N - 1 - decltype(kc)::value;
+            constexpr int I = k / SPT, pp = k % SPT;
+            const double v = mm4(Lt, Bpl[pp]);
+            if constexpr (LPI == 16) ap[I][pp] = v;
+            else ap[I / 4][pp] = (g == I % 4) ? v : ap[I / 4][pp];
+            if constexpr (k > 0) Lt = mm4(A, mm4(Lt, A), Q);
+        });
+        double Rd = 0.0;                                              // R on the diagonal blocks of a diagonal tile
+#pragma unroll
+        for (int qq = 0; qq < SPT; ++qq) {
+            const int rr = r - qq * NU, cc = c - qq * NU;
+            const bool v = rr >= 0 && rr < NU && cc >= 0 && cc < NU;
+            const double x = sh[p.so.R + (v ? rr * NU + cc : 0)];
+            Rd = v ? x : Rd;
+        }
+        double X = Bpl[0];                                            // X_d = [A^d B | A^(d-1) B | ..] (columns of negative powers: zero)
+        sfor<0, NT>([&](auto Dc) {
+            constexpr int D = decltype(Dc)::value;
+            double acc[NTM];
+#pragma unroll
+            for (int m = 0; m < NTM; ++m) acc[m] = (D == 0) ? Rd : 0.0;
+            sfor<0, SPT>([&](auto pc) {
+                constexpr int pp = decltype(pc)::value;
+                constexpr int d = D * SPT + pp;
+                if constexpr (d > 0) X = mm4(At, X, d <= SPT - 1 ? Bpl[d <= SPT - 1 ? d : 0] : 0.0);
+                if constexpr (LPI == 16) {
+                    sfor<D, NT>([&](auto Ic) { constexpr int I = decltype(Ic)::value; acc[I] = mm4(ap[I][pp], X, acc[I]); });
+                } else {
+                    sfor<D / 4, NTM>([&](auto mc) { constexpr int m = decltype(mc)::value; acc[m] = mm4(ap[m][pp], X, acc[m]); });
+                }
+            });
+            if constexpr (LPI == 16) {
+                sfor<D, NT>([&](auto Ic) { constexpr int I = decltype(Ic)::value; store_tile(Pp, dP, I, I - D, 2.0 * acc[I], true); });
+            } else {
+                sfor<D / 4, NTM>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    const int I = 4 * m + g;
+                    store_tile(Pp, dP, I, I - D, 2.0 * acc[m], I >= D && I < NT);
+                });
+            }
+        });
+    }
+    __syncthreads();
+}
+
+}  // namespace lqmpc
