@@ -63,6 +63,9 @@ def parse_args(argv=None):
                     help="collective backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse the sharded path on one GPU)")
     ap.add_argument("--all-on-gpu0", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--dump", default="", help="rank 0 saves the gathered J_T of the last rollout to this .npy (tests)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="--gpus 1 only: initialise a world-size-1 process group and take the multi-rank code path (RCCL init on the "
+                         "device, device-side all_gather_into_tensor, barrier, all_reduce) -- the calls an N-GPU launch makes")
     return ap.parse_args(argv)
 
 
@@ -70,7 +73,9 @@ def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run as a CHILD process (this process
     has not touched the GPU), relay its output and exit with its code."""
     import torch
-    have = torch.cuda.device_count()                  # does not initialise the GPU
+    # (device_count() may bring up the HIP runtime in THIS process on some builds; the ranks are fresh child processes, which is
+    # allowed -- but never run this launcher under rocprofv3: tools/prof.sh refuses --gpus > 1)
+    have = torch.cuda.device_count()
     if not args.all_on_gpu0 and have < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible", file=sys.stderr)
         sys.exit(2)
@@ -104,9 +109,12 @@ def main():
     if args.all_on_gpu0:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    distributed = world > 1 or args.force_dist          # the collective path (a world of one rank still runs every call of it)
+    if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:              # (--force-dist without a launcher)
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1]); sk.close()
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -126,9 +134,9 @@ def main():
     # overheads and not a change of workload.
     Bglobal = cfg["Bsz"] if strong else world * (args.bsz or cfg["Bsz"])
     gb = synth.make_batch(args.config, Bsz=Bglobal, fixture_dir=gold, mix=args.mix)
-    b = ld.shard_batch(gb, rank, world) if world > 1 else gb
+    b = ld.shard_batch(gb, rank, world) if distributed else gb
     Bsz = b["A"].shape[-1]
-    lo = b["shard"][0] if world > 1 else 0
+    lo = b["shard"][0] if distributed else 0
     del gb
 
     dA = torch.from_numpy(b["A"]).to(dev); dB = torch.from_numpy(b["B"]).to(dev); dx0 = torch.from_numpy(b["x0"]).to(dev)
@@ -157,7 +165,7 @@ def main():
         src = dJT if cdev.type == "cuda" else dJT.cpu()              # gloo rehearsal: through host memory
         gathered["J"] = ld.all_gather_costs(src, Bglobal)
 
-    if world > 1 and args.gather == "per-step":
+    if distributed and args.gather == "per-step":
         # the collective of step k runs while the rollout of step k+1 computes: J_T is copied to one of two staging buffers on the
         # launch stream, gathered asynchronously from it and waited for one step later (and before the timed region closes)
         sizes = [ld.shard_bounds(Bglobal, r, world) for r in range(world)]
@@ -179,8 +187,8 @@ def main():
             gathered["pending"] = None
 
     def run(launch, steps, warmup, qp_per_launch, with_gather=True):
-        per_step = world > 1 and with_gather and args.gather == "per-step"
-        final = world > 1 and with_gather and args.gather == "final"
+        per_step = distributed and with_gather and args.gather == "per-step"
+        final = distributed and with_gather and args.gather == "final"
         for _ in range(warmup):
             launch()
             if per_step:
@@ -193,7 +201,7 @@ def main():
         # between consecutive launches and costs ~8 % of a 0.47 ms step); recorded BEFORE the gather, so that the kernel
         # time of the roofline holds no collective
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -210,11 +218,11 @@ def main():
             gather_final()
             torch.cuda.synchronize()
             gathered["ms"] = (time.perf_counter() - tg) * 1e3        # includes waiting for this rank's last rollout
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if distributed:
             tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -224,7 +232,7 @@ def main():
     def totals():
         """(sum of iters, instances with non-zero status) over all ranks."""
         agg = torch.tensor([float(dit.double().sum().item()), float((dst != 0).sum().item())], dtype=torch.float64, device=cdev)
-        if world > 1:
+        if distributed:
             dist.all_reduce(agg)
         return float(agg[0].item()), int(agg[1].item())
 
@@ -238,8 +246,8 @@ def main():
     iters_mean = iters_total / qp_global
 
     gather_info = None
-    if world > 1:
-        gather_info = {"mode": args.gather, "collective": "all_gather_into_tensor (lq_mpc_amd.dist.all_gather_costs)",
+    if distributed:
+        gather_info = {"mode": args.gather, "world_size": world, "collective": "all_gather_into_tensor (lq_mpc_amd.dist.all_gather_costs)",
                        "backend": args.backend + (" (RCCL)" if args.backend == "nccl" else " (rehearsal)"),
                        "bytes_per_rank": 8 * Bsz}
         if args.gather == "final":
@@ -250,6 +258,15 @@ def main():
             gather_info["J_T_sum"] = float(J.double().sum().item())
             if args.dump and rank == 0:
                 np.save(args.dump, J.cpu().numpy())
+        else:
+            k = (gathered["k"] - 1) & 1                  # the last per-step gather (flushed before the timed region closed)
+            J = out_bufs[k]
+            m_ = stage_bufs[k].numel()
+            mine = J[rank * m_: rank * m_ + Bsz].to(dev)
+            gather_info["own_shard_intact"] = bool(torch.equal(mine, dJT))
+            if args.dump and rank == 0:
+                sizes_ = [ld.shard_bounds(Bglobal, r_, world) for r_ in range(world)]
+                np.save(args.dump, torch.cat([J[r_ * m_: r_ * m_ + (hi_ - lo_)] for r_, (lo_, hi_) in enumerate(sizes_)]).cpu().numpy())
     elif args.dump:
         np.save(args.dump, dJT.cpu().numpy())
 
@@ -262,6 +279,10 @@ def main():
         tflops = f_step * qp_launch / (kernel_ms * 1e-3) / 1e12
         gbs = alg_bytes * (qp_launch / per) / (kernel_ms * 1e-3) / 1e9
         return f_step, alg_bytes, tflops, gbs
+
+    def f_step_no_setup(iters_mean):
+        """SURVEY 8(d)'s rollout formula read literally: iters * F_it(n) + 2 n n_x, no condensing term."""
+        return iters_mean * f_iter(n) + 2 * n * nx
 
     f_step, alg_bytes, tflops, gbs = roofline_of(kernel_ms, iters_mean, args.mode, qp_local)
     # HBM traffic per launch: the PMC counters cannot be read from inside this process; the figure is the committed rocprofv3
@@ -285,16 +306,22 @@ def main():
     wg = "wg" in kernel_name
     roofline = {
         "kernel": kernel_name, "bound": "mfma",
-        "unit_executing": "mfma_f64 (block products) + valu_fp64" if wg else "valu_fp64 (no MFMA issued: DPP/VALU fp64 FMAs)",
+        "unit_executing": "mfma_f64 16x16x4 (block products) + valu_fp64" if wg else
+                          ("mfma_f64 4x4x4 (set-up: Riccati recursion, W, P, G) + valu_fp64 / DPP (active-set iterations, closed loop)"
+                           if "r16" in kernel_name or "r64" in kernel_name else "valu_fp64"),
         "bound_detail": "fp64 compute roof: 78.6 TFLOP/s dense, the same for the vector ALU and v_mfma_f64 ('mfma' is the contract's "
                         "name for the compute roof; unit_executing says which unit runs this kernel)",
         "achieved": round(tflops, 4), "peak": FP64_PEAK_TFLOPS,
-        "unit": "TFLOP/s", "frac": round(tflops / FP64_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_source,
+        "unit": "TFLOP/s", "frac": round(tflops / FP64_PEAK_TFLOPS, 5),
+        "frac_no_setup": round(f_step_no_setup(iters_mean) * qp_local / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5),
+        "flops_per_qp_step_no_setup": round(f_step_no_setup(iters_mean), 1),
+        "traffic": traffic, "traffic_source": traffic_source,
         "kernel_ms_per_launch": round(kernel_ms, 4), "iters_mean": round(iters_mean, 3),
         "flops_per_qp_step": round(f_step, 1), "alg_bytes_per_instance": alg_bytes,
         "hbm": {"achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 7)},
         "note": "the fp64 compute roof binds (SURVEY 8(d)): ~250 B of unique HBM traffic vs ~40 kflop per QP-step; "
-                "flops = iters_mean*(n^3/3+6n^2)+2*n*nx+condensing/T; iters_mean = KKT factorisations per QP-step "
+                "flops = iters_mean*(n^3/3+6n^2)+2*n*nx+condensing/T (frac) or without the condensing term (frac_no_setup: SURVEY 8(d)'s "
+                "rollout formula read literally); iters_mean = KKT factorisations per QP-step "
                 "(interior-point + active-set iterations; 0 for steps the presolve finishes); kernel time = HIP events around "
                 "the K launches of this rank, collectives excluded",
     }
@@ -365,6 +392,81 @@ def main():
                                "dlqr_not_converged": int((dstb == 1).sum().item()) + int((dstb == 2).sum().item()),
                                "workload": "lqmpc_bounds_batch_dev: dlqr (doubling) + local radius + stability numbers + alpha/beta/xi/eta/bound "
                                            "per system (utils_class.py:837-859), one instance per lane; Householder tridiagonalisation + bisection for the two N n_u x N n_u eigenproblems"}
+        if args.config != 1:
+            # the engine north_star names, alone: Mehrotra interior point + active-set polish, no warm start, no presolve shortcut
+            # beyond the default (options.warm_start = 0)
+            s.set_options(warm_start=0)
+            try:
+                dti, kmsi, vi = run(launch_rollout, max(args.steps // 4, 3), 1, qp_local)
+                iti, bad_i = totals()
+            finally:
+                s.set_options(warm_start=-1)
+            fsi, _, tfli, _ = roofline_of(kmsi, iti / qp_local, "rollout", qp_local)
+            extra["ipm_only"] = {"value": round(vi, 1), "unit": "QP-steps/s", "kernel_ms_per_launch": round(kmsi, 4),
+                                 "iters_mean": round(iti / qp_local, 3), "status_nonzero": bad_i, "kernel": s.last_kernel(),
+                                 "flops_per_qp_step": round(fsi, 1), "roofline_frac": round(tfli / FP64_PEAK_TFLOPS, 5),
+                                 "workload": "the headline rollout with options.warm_start = 0: every QP the presolve does not finish goes "
+                                             "through the primal-dual interior-point loop + exact polish"}
+        # PCIe: the headline batch's inputs host -> device and its result back (pinned host memory), never part of `value`
+        hA, hB, hx = (torch.from_numpy(b[k]).pin_memory() for k in ("A", "B", "x0"))
+        hJ = torch.empty(Bsz, dtype=torch.float64).pin_memory()
+        tA, tB, tx = torch.empty_like(dA), torch.empty_like(dB), torch.empty_like(dx0)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        h2d, d2h = [], []
+        for _ in range(4):
+            e0.record(); tA.copy_(hA, non_blocking=True); tB.copy_(hB, non_blocking=True); tx.copy_(hx, non_blocking=True); e1.record()
+            hJ.copy_(dJT, non_blocking=True); e2.record(); torch.cuda.synchronize()
+            h2d.append(e0.elapsed_time(e1)); d2h.append(e1.elapsed_time(e2))
+        in_bytes = 8 * (tA.numel() + tB.numel() + tx.numel())
+        h2d_ms, d2h_ms = min(h2d), min(d2h)
+        extra["pcie"] = {"h2d_ms": round(h2d_ms, 4), "d2h_ms": round(d2h_ms, 4), "h2d_bytes": in_bytes, "d2h_bytes": 8 * Bsz,
+                         "h2d_GBps": round(in_bytes / (h2d_ms * 1e-3) / 1e9, 2),
+                         "value_pcie_inclusive": round(qp_local / ((h2d_ms + kernel_ms + d2h_ms) * 1e-3), 1),
+                         "note": "A, B, x0 of the headline batch from pinned host memory, J_T back; HIP events, best of 4; "
+                                 "value_pcie_inclusive = QP-steps / (h2d + one launch + d2h), reported beside `value`, never as it"}
+        del tA, tB, tx
+        # closed-loop rollouts of small batches: us per MPC step (the reference runs ONE system per simulate(), utils_class.py:245-285)
+        small = {}
+        for m in (1, 64, 4096):
+            if m > Bsz:
+                continue
+            mA, mB, mx = (torch.from_numpy(np.ascontiguousarray(b[k][..., :m])).to(dev) for k in ("A", "B", "x0"))
+            mJ = torch.empty(m, dtype=torch.float64, device=dev)
+            for _ in range(3):
+                s.rollout_batch_dev(nx, nu, N, m, T, mA, mB, *shared, mx, b["A_true"], b["B_true"], mJ)
+            s.timer_begin()
+            for _ in range(20):
+                s.rollout_batch_dev(nx, nu, N, m, T, mA, mB, *shared, mx, b["A_true"], b["B_true"], mJ)
+            us = s.timer_end() / 20 * 1e3
+            small[str(m)] = {"rollout_us": round(us, 1), "us_per_mpc_step": round(us / T, 3), "kernel": s.last_kernel()}
+        extra["rollout_small_batches"] = {"by_batch": small, "T": T, "note": "lqmpc_rollout_batch_dev on the first m systems, resident "
+                                          "data, back-to-back launches, HIP events; one launch = T dependent MPC steps"}
+        # the reference's own workload end to end: LQ_RDP_Behavior_Multiple.data_generation (utils_class.py:766-959), 57 001 QPs +
+        # the bound coefficients of 1 500 systems, through the host API (numpy in / out, 6 sweep + 6 bounds calls + 2 small ones)
+        try:
+            from lq_mpc_amd.sweep import LQ_RDP_Behavior_Multiple
+            info_opc = {"A": synth.A_REF, "B": synth.B_REF, "Q": 2.0 * np.eye(2), "R": np.eye(1), "F_u": np.array([[10.0], [-10.0]])}
+            info_N = {"N_min": 6, "N_max": 10, "N_nominal": 7, "N_opc": 30, "N_mpc": 30}
+            info_e = {"e_min": 1e-3, "e_max": 1e-2, "e_nominal": 5e-3}
+            info_ref = {"x_ref": np.zeros((2, 7)), "u_ref": np.zeros((1, 7)), "x_ref_long": np.zeros((2, 30)), "u_ref_long": np.zeros((1, 30))}
+            sdg = BatchSolver(local_rank)
+            beh = LQ_RDP_Behavior_Multiple(info_opc, info_N, info_e, 20, "f", data_dir=gold, solver=sdg)
+            pdg = np.array([0.1, 1.0, 0.6])
+            beh.data_generation(8, 1.5, info_ref, pdg)
+            tw = []
+            for _ in range(5):
+                t0 = time.perf_counter(); og = beh.data_generation(8, 1.5, info_ref, pdg); tw.append(time.perf_counter() - t0)
+            ref_npz = np.load(os.path.join(gold, "data_lq_mpc_multipleSys.npz"))
+            dev_ = float(np.max(np.abs(og["true_cost_error"] - ref_npz["true_cost_error"]) / np.abs(ref_npz["true_cost_error"])))
+            sdg.close()
+            extra["data_generation"] = {"wall_ms": round(min(tw) * 1e3, 3), "wall_ms_median": round(sorted(tw)[len(tw) // 2] * 1e3, 3),
+                                        "qp_solves": 57001, "value": round(57001 / min(tw), 1), "unit": "QP-steps/s",
+                                        "true_cost_error_max_rel_dev_vs_reference_npz": dev_,
+                                        "workload": "lq_mpc_amd.sweep.LQ_RDP_Behavior_Multiple.data_generation on the reference's inputs "
+                                                    "(error_{A,B}_f.npy, working_example_multiple.py constants): 1 500 systems x (8 open-loop "
+                                                    "+ 30 closed-loop QPs) + V_expert + the 13 npz arrays, host API, wall clock"}
+        except Exception as e:                                          # (never at the price of the bench line)
+            extra["data_generation"] = {"error": repr(e)}
         # single-call latency: the reference's call shape is ONE instance per solve() (utils_class.py:269)
         lat = {}
         for m in (1, 64, 4096):
@@ -391,35 +493,46 @@ def main():
                                     "sync (what LQ_MPC_Controller.solve costs per call at m = 1); solve_batch_dev: back-to-back "
                                     "launches on resident data, HIP events"}
 
-    # ---- CPU baseline: the oracle (port), all host cores, bounded sample, rank 0 at N=1 only ----
+    # ---- CPU baseline: the oracle (port) at 1 thread, --cpu-threads and all host cores; bounded samples; rank 0 at N=1 only ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
+        native = orc.use_native_build()                    # gcc -O3 -march=native on THIS host (falls back to the shipped x86-64-v3 build)
         avail = len(os.sched_getaffinity(0))
-        cores = max(1, min(avail, args.cpu_threads or avail))
 
-        def cpu_run(m):
+        def cpu_run(m, threads):
             A = np.ascontiguousarray(b["A"][:, :, :m]); Bm = np.ascontiguousarray(b["B"][:, :, :m])
             x0 = np.ascontiguousarray(b["x0"][:, :m])
             t = time.perf_counter()
             if args.mode == "rollout":
-                orc.rollout_batch(T, N, A, Bm, *shared, x0, b["A_true"], b["B_true"], threads=cores)
+                orc.rollout_batch(T, N, A, Bm, *shared, x0, b["A_true"], b["B_true"], threads=threads)
                 q = m * T
             else:
-                orc.solve_batch(N, A, Bm, *shared, x0, threads=cores)
+                orc.solve_batch(N, A, Bm, *shared, x0, threads=threads)
                 q = m
             return q, time.perf_counter() - t
-        m0 = min(Bsz, 256)
-        q0, t0 = cpu_run(m0)
-        m = int(min(Bsz, max(m0, m0 * 2.0 / max(t0, 1e-3))))       # ~2 s of wall per pass when the batch allows
-        q, t, reps = 0, 0.0, 0
-        while t < 1.0 and reps < 50:                               # >= 1 s of wall on `cores` threads (~16 core-seconds)
-            qi, ti = cpu_run(m)
-            q += qi; t += ti; reps += 1
-        cpu = {"value": round(q / t, 1), "unit": "QP-steps/s", "cores": cores, "kind": "port",
+
+        def cpu_leg(threads, wall=1.0):
+            m0 = int(min(Bsz, max(16, 16 * threads)))
+            q0, t0 = cpu_run(m0, threads)
+            m = int(min(Bsz, max(m0, m0 * wall / max(t0, 1e-4))))   # ~`wall` seconds per pass when the batch allows
+            q, t, reps = 0, 0.0, 0
+            while t < wall and reps < 50:
+                qi, ti = cpu_run(m, threads)
+                q += qi; t += ti; reps += 1
+            return {"value": round(q / t, 1), "unit": "QP-steps/s", "cores": threads,
+                    "sample": f"first {m} instances of the same batch x {reps} passes ({q} QP-steps, {t:.2f} s wall, {t * threads:.0f} core-seconds)"}
+        legs = {}
+        for th in sorted({1, max(1, min(avail, args.cpu_threads or avail)), avail}):
+            legs[th] = cpu_leg(th, wall=2.0 if th == 1 else 1.0)
+        best = max(legs, key=lambda k: legs[k]["value"])      # (a shared box: "all cores" can be slower than one GPU's share of them)
+        top = legs[best]
+        cpu = {"value": top["value"], "unit": "QP-steps/s", "cores": best, "kind": "port",
                "nproc": os.cpu_count(), "cores_available_to_process": avail,
-               "sample": f"first {m} instances of the same batch x {reps} passes ({q} QP-steps, {t:.2f} s wall, "
-                         f"{t * cores:.0f} core-seconds), exact active-set oracle (oracle/lqmpc_oracle.c), OpenMP over instances; "
+               "build": "gcc -O3 -march=native -fopenmp on this host" if native else "shipped build (-march=x86-64-v3): no compiler on this host",
+               "single_thread": legs[1], "all_cores": legs[avail], "by_threads": {str(k): v for k, v in legs.items()},
+               "sample": top["sample"] + "; exact active-set oracle (oracle/lqmpc_oracle.c), OpenMP over instances; `value` = the best of "
+                         "the thread counts tried (1, --cpu-threads, every core this process may use: by_threads), `cores` = its threads; "
                          "the reference's cvxpy path is not measurable in this pipeline (cvxpy absent, SURVEY 8(d))"}
 
     if rank == 0:
@@ -447,7 +560,7 @@ def main():
         out.update(extra)
         print(json.dumps(out), flush=True)
     s.close()
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -76,10 +76,16 @@ enum lqmpc_kernel {
     LQMPC_KERNEL_GENERIC = 1,     /* any dims up to the limits; one instance per lane, workspace in HBM */
     LQMPC_KERNEL_SPECIALIZED = 2, /* fail with LQMPC_ERR_UNSUPPORTED if no specialisation exists */
     LQMPC_KERNEL_WORKGROUP = 3    /* one instance per 256-thread workgroup, matrices in LDS (32 < N*nu <= 128, nx <= 16,
-                                     nu <= 8, LDS image within 160 KiB); LQMPC_ERR_UNSUPPORTED otherwise */
+                                     nu <= LQMPC_MAX_NU, LDS image within 160 KiB); LQMPC_ERR_UNSUPPORTED otherwise */
 };
 
+/* ABI note (library 0.2.0): the struct starts with its own size.  lqmpc_default_options / lqmpc_get_options fill it in;
+ * lqmpc_set_options rejects a struct whose struct_size is not the library's sizeof(lqmpc_options) -- a caller built against another
+ * version of this header gets LQMPC_ERR_BAD_ARG instead of the library reading past its struct.  Always start from
+ * lqmpc_default_options() or lqmpc_get_options(). */
 typedef struct lqmpc_options {
+    uint32_t struct_size; /* sizeof(lqmpc_options) of the header the caller was built against */
+    uint32_t reserved;    /* 0 */
     double eps;        /* relative tolerance on complementarity gap and dual residual (default 1e-12) */
     double tau;        /* fraction-to-the-boundary of the interior-point step (default 0.999) */
     double z0_scale;   /* initial multipliers = z0_scale * |q|_inf (default 0.1) */

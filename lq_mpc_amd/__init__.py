@@ -6,4 +6,4 @@ loops that drive them) as hand-written HIP kernels for gfx950; see DESIGN.md.
 from .mpc import BatchSolver, LQ_MPC_Controller, LQ_MPC_Simulator, box_from_Fu, default_solver  # noqa: F401
 from ._lib import LqmpcError, KERNEL_AUTO, KERNEL_GENERIC, KERNEL_SPECIALIZED, KERNEL_WORKGROUP  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

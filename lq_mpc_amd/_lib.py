@@ -31,7 +31,7 @@ EXPORTS = [
 
 
 class Options(ctypes.Structure):
-    _fields_ = [("eps", ctypes.c_double), ("tau", ctypes.c_double), ("z0_scale", ctypes.c_double),
+    _fields_ = [("struct_size", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("eps", ctypes.c_double), ("tau", ctypes.c_double), ("z0_scale", ctypes.c_double),
                 ("max_iter", ctypes.c_int32), ("polish", ctypes.c_int32), ("kernel", ctypes.c_int32),
                 ("presolve", ctypes.c_int32), ("order", ctypes.c_int32), ("warm_start", ctypes.c_int32),
                 ("layout", ctypes.c_int32), ("r16_maxit", ctypes.c_int32), ("r16_build", ctypes.c_int32),

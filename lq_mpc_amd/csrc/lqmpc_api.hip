@@ -119,9 +119,19 @@ static int ensure(lqmpc_handle *h, DevBuf &b, size_t bytes)
     return 0;
 }
 
+// The buffer that holds the hand-back count, the order's counters and the hand-back list.  A re-allocated buffer holds undefined
+// counters (hipMalloc may even hand the old address back), so the no-fill path of build_order is switched off by CAPACITY.
+static int ensure_fail(lqmpc_handle *h, size_t bytes)
+{
+    const size_t cap_before = h->fail.cap;
+    const int rc = ensure(h, h->fail, bytes);
+    if (h->fail.cap != cap_before || rc) h->hist_ready = false;
+    return rc;
+}
+
 extern "C" {
 
-const char *lqmpc_version(void) { return "lqmpc-mi355x 0.1.0 (gfx950, fp64)"; }
+const char *lqmpc_version(void) { return "lqmpc-mi355x 0.2.0 (gfx950, fp64)"; }
 const char *lqmpc_last_error(void) { return g_err.c_str(); }
 
 int lqmpc_device_count(void)
@@ -134,6 +144,8 @@ int lqmpc_device_count(void)
 void lqmpc_default_options(lqmpc_options *opt)
 {
     if (!opt) return;
+    opt->struct_size = (uint32_t)sizeof(lqmpc_options);
+    opt->reserved = 0;
     opt->eps = 1e-12;
     opt->tau = 0.999;
     opt->z0_scale = 0.1;
@@ -212,6 +224,9 @@ int lqmpc_sync(lqmpc_handle *h)
 int lqmpc_set_options(lqmpc_handle *h, const lqmpc_options *opt)
 {
     if (!h || !opt) return fail(LQMPC_ERR_BAD_ARG, "NULL argument");
+    if (opt->struct_size != sizeof(lqmpc_options))
+        return fail(LQMPC_ERR_BAD_ARG, "lqmpc_options.struct_size does not match this library: built against another lqmpc.h? "
+                                       "(start from lqmpc_default_options / lqmpc_get_options)");
     if (!(opt->eps > 0.0 && opt->eps < 1.0)) return fail(LQMPC_ERR_BAD_ARG, "eps must be in (0,1)");
     if (!(opt->tau > 0.0 && opt->tau < 1.0)) return fail(LQMPC_ERR_BAD_ARG, "tau must be in (0,1)");
     if (!(opt->z0_scale > 0.0)) return fail(LQMPC_ERR_BAD_ARG, "z0_scale must be positive");
@@ -386,7 +401,7 @@ static int prepare(lqmpc_handle *h, const Call &c, KParams &p)
     h->use_wg = !use_spec(h, nx, nu, N) && (h->opt.kernel == LQMPC_KERNEL_AUTO || h->opt.kernel == LQMPC_KERNEL_WORKGROUP) &&
                 lqmpc::wg_supported(p, c.lb, c.ub);
     if (h->opt.kernel == LQMPC_KERNEL_WORKGROUP && !h->use_wg)
-        return fail(LQMPC_ERR_UNSUPPORTED, "the workgroup kernel needs 32 < N*nu <= 128, nx <= 16 and an LDS image within 160 KiB");
+        return fail(LQMPC_ERR_UNSUPPORTED, "the workgroup kernel needs 32 < N*nu <= 128, nx <= 16, nu <= 8 and an LDS image within 160 KiB");
     if (!use_spec(h, nx, nu, N) && !h->use_wg) {
         p.ws_stride = (c.Bsz + 63) / 64 * 64;
         const size_t bytes = (size_t)lqmpc::generic_ws_entries(nx, nu, N) * (size_t)p.ws_stride * sizeof(double);
@@ -409,15 +424,13 @@ static int build_order(lqmpc_handle *h, KParams &p)
     if (B > (size_t)INT32_MAX) return fail(LQMPC_ERR_BAD_ARG, "ordering supports up to 2^31-1 instances");
     int rc = ensure(h, h->key, B * sizeof(double));
     if (!rc) rc = ensure(h, h->perm, B * sizeof(int));
-    const void *fail_before = h->fail.p;
-    if (!rc) rc = ensure(h, h->fail, ((size_t)p.Bsz + FAIL_HDR) * sizeof(int));
+    if (!rc) rc = ensure_fail(h, ((size_t)p.Bsz + FAIL_HDR) * sizeof(int));
     const size_t rec_doubles = (size_t)(p.nx * p.nx + p.nx * p.nu + p.nx);
     if (!rc) rc = ensure(h, h->rec, B * rec_doubles * sizeof(double));
     if (rc) return rc;
     // The hand-back count and the order's counters.  First call (or a new buffer): one fill of everything.  After that the probe
     // launch itself zeroes the count and the set of counters the NEXT call will use (the sets alternate), so a call costs no fill
     // launch (4 us of a 0.39 ms C3 call).  Any failure below leaves hist_ready false: the next call fills again.
-    if (h->fail.p != fail_before) h->hist_ready = false;
     if (!h->hist_ready) {
         HIP_TRY(hipMemsetAsync(h->fail.p, 0, FAIL_HDR * sizeof(int), h->stream));
         h->hist_turn = 0;
@@ -476,7 +489,7 @@ static bool use_r16(const lqmpc_handle *h, const KParams &p, int64_t Bsz, int64_
 // the hand-back list of this call: count zeroed (by build_order's fill if it ran), list behind the order's counters
 static int prepare_hand_back(lqmpc_handle *h, KParams &p)
 {
-    int rc = ensure(h, h->fail, ((size_t)p.Bsz + FAIL_HDR) * sizeof(int));
+    int rc = ensure_fail(h, ((size_t)p.Bsz + FAIL_HDR) * sizeof(int));
     if (rc) return rc;
     if (!h->fail_cleared) HIP_TRY(hipMemsetAsync(h->fail.p, 0, 2 * sizeof(int), h->stream));
     h->fail_cleared = false;

@@ -92,7 +92,7 @@ size_t wg_lds_bytes(int nx, int nu, int N) { return (size_t)wg_offsets(nx, nu, N
 bool wg_supported(const KParams &p, const double *lb, const double *ub)
 {
     (void)lb; (void)ub;
-    if (p.n <= 32 || p.n > 128 || p.nx > 16 || p.nu > 64) return false;      // (nx, nu: the closed-loop update lives in one wavefront)
+    if (p.n <= 32 || p.n > 128 || p.nx > 16 || p.nu > 8) return false;      // (nx, nu: the closed-loop update lives in one wavefront)
     const WgOff o = wg_offsets(p.nx, p.nu, p.N);
     return o.total <= LDS_DOUBLES && o.smax >= 1;
 }

@@ -83,8 +83,11 @@ class LQ_RDP_Behavior_Multiple:
             nx = self.A_true.shape[0]
             r = self._s().bounds_batch(1, self.A_true[:, :, None], self.B_true[:, :, None], self.Q, self.R, self.lb, self.ub,
                                        0.0, 0.0, None, np.zeros(nx), np.ones(3), 0.0)
-            if r["status"][0] != 0:
-                raise RuntimeError("dlqr of the true system did not converge (not stabilisable?)")
+            # status 3 = the bound formulas leave the reals (rho(A - BK) + 0.4 > 1, utils.py:358) -- K and eps are valid there, and
+            # the reference computes local_radius for any stabilisable system (utils_class.py:761-764)
+            if r["status"][0] not in (0, 3):
+                raise RuntimeError(f"dlqr of the true system failed (lqmpc_bounds_batch status {int(r['status'][0])}: "
+                                   "1 = doubling iteration not settled, 2 = not stabilisable)")
             self._eps_lqr, self.K_lqr = float(r["eps"][0]), r["K"][:, :, 0].copy()
         return self._eps_lqr
 
@@ -92,7 +95,9 @@ class LQ_RDP_Behavior_Multiple:
         """alpha, beta, xi, bound for a batch of models sharing horizon N (utils_class.py:837-859): one launch."""
         r = self._s().bounds_batch(N, A_stack, B_stack, self.Q, self.R, self.lb, self.ub, e_level, e_level, M_V, x_start, p, V_expert)
         if np.any(r["status"] != 0):
-            raise RuntimeError(f"lqmpc_bounds_batch: {int(np.sum(r['status'] != 0))} models without a stabilising dlqr gain")
+            cnt = {int(k): int(np.sum(r["status"] == k)) for k in np.unique(r["status"]) if k != 0}
+            raise RuntimeError(f"lqmpc_bounds_batch: models per non-zero status {cnt} (1 = dlqr doubling not settled, 2 = not "
+                               "stabilisable, 3 = the bound formulas leave the reals: rho(A - BK) + 0.4 > 1, utils.py:358)")
         return r["alpha"], r["beta"], r["xi"], r["bound"]
 
     def data_generation(self, N_points, ext_radius_max, info_ref, p=None, save_path=None):

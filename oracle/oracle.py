@@ -46,6 +46,24 @@ def lib():
     return _lib
 
 
+def use_native_build():
+    """bench.py's cpu_baseline leg: rebuild the oracle with -march=native for the host it is timed on (into a temp directory;
+    the shipped library stays as it is) and switch this module to it.  Returns False (and keeps the shipped build) when no
+    compiler is available."""
+    global _lib
+    import tempfile
+    try:
+        out = os.path.join(tempfile.mkdtemp(prefix="lqmpc_oracle_native_"), "liblqmpc_oracle_native.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-fopenmp", "-std=c11", "-shared", "-o", out,
+                               os.path.join(_HERE, "lqmpc_oracle.c"), "-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        nat = ctypes.CDLL(out)
+        nat.lqo_num_threads.restype = ctypes.c_int
+        _lib = nat
+        return True
+    except Exception:
+        return False
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(_D)
 

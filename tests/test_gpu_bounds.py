@@ -122,3 +122,25 @@ def test_unstabilisable_model_is_reported(solver):
         solver.bounds_batch(5, A, B, Q2, -R1, [-0.1], [0.1], 1e-3, 1e-3, 1.0, np.ones(2), np.ones(3), 1.0)     # R not SPD
     with pytest.raises(Exception):
         solver.bounds_batch(5, A, B, Q2, R1, [0.0], [0.1], 1e-3, 1e-3, 1.0, np.ones(2), np.ones(3), 1.0)      # a zero bound is no row of F_u
+
+
+def test_slowly_damped_true_system_keeps_its_radius(solver):
+    """A true system whose LQR closed loop has rho(A - BK) + 0.4 > 1: the bound formulas leave the reals (status 3, utils.py:358)
+    but K and the local radius are valid, and the reference computes local_radius for any stabilisable system
+    (utils_class.py:761-764): epsilon_lqr and circle_generator must work."""
+    from lq_mpc_amd.sweep import LQ_RDP_Behavior_Multiple, circle_generator
+    A = np.array([[1.02, 0.3], [0.0, 0.97]]); B = np.array([[0.05], [0.1]])
+    Q, R = 0.02 * np.eye(2), 4.0 * np.eye(1)
+    K, _ = orc.dlqr_gain(A, B, Q, R)
+    rho = np.max(np.abs(np.linalg.eigvals(A - B @ K)))
+    assert 0.6 < rho < 1.0
+    beh = LQ_RDP_Behavior_Multiple.__new__(LQ_RDP_Behavior_Multiple)
+    beh.A_true, beh.B_true, beh.Q, beh.R = A, B, Q, R
+    beh.lb, beh.ub = np.array([-0.1]), np.array([0.1])
+    beh._solver, beh._eps_lqr = solver, None
+    eps = beh.epsilon_lqr
+    F_u = np.array([[10.0], [-10.0]])
+    assert abs(eps - orc.local_radius(F_u, -K, Q)) <= 1e-9 * eps
+    assert np.max(np.abs(beh.K_lqr - K)) <= 1e-9 * np.max(np.abs(K))
+    pts = circle_generator(8, 1.5, eps, Q)
+    assert pts.shape == (2, 8) and np.all(np.isfinite(pts))

@@ -563,3 +563,27 @@ def test_c4_eight_way_sharded_form_equals_the_single_batch(solver, golden_dir):
     sub = dict(b, A=np.ascontiguousarray(b["A"][:, :, idx]), B=np.ascontiguousarray(b["B"][:, :, idx]))
     ref = orc.rollout_batch(30, *args(sub), np.ascontiguousarray(b["x0"][:, idx]), b["A_true"], b["B_true"])
     assert rel(full["J_T"][idx], ref["J_T"]) < TIGHT
+
+
+def test_ordered_rollout_growing_batch_on_one_handle(golden_dir):
+    """A handle that has run an ordered (probe + bucket order) rollout re-allocates its counter / hand-back buffer when the batch
+    grows: the no-fill path of the order counters must notice (by capacity, not by address) and refill, or the scatter writes out
+    of bounds.  8 192 then 65 536 instances on the SAME fresh handle, each against a separate handle's natural-order run."""
+    s = BatchSolver(0)
+    s2 = BatchSolver(0, order=0)
+    try:
+        for bsz in (8192, 65536, 8192):
+            b = synth.make_batch(3, Bsz=bsz, fixture_dir=golden_dir)
+            a = (*args(b), b["x0"], b["A_true"], b["B_true"])
+            g = s.rollout_batch(12, *a)
+            r = s2.rollout_batch(12, *a)
+            assert np.all(g["status"] == 0) and np.all(r["status"] == 0)
+            assert rel(g["J_T"], r["J_T"]) < 1e-12
+        m = 512
+        b = synth.make_batch(3, Bsz=65536, fixture_dir=golden_dir)
+        ref = orc.rollout_batch(12, b["N"], b["A"][:, :, :m].copy(), b["B"][:, :, :m].copy(), b["Q"], b["R"], b["P"], b["lb"], b["ub"],
+                                b["x0"][:, :m].copy(), b["A_true"], b["B_true"])
+        g = s.rollout_batch(12, *args(b), b["x0"], b["A_true"], b["B_true"])
+        assert rel(g["J_T"][:m], ref["J_T"]) < TIGHT
+    finally:
+        s.close(); s2.close()

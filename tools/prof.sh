@@ -3,6 +3,8 @@
 # kernel-trace stats, then separate PMC passes (never combined with trace domains other than kernel-trace).
 set -o pipefail
 TAG=$1; shift
+# one process only: rocprofv3's preloaded runtime has initialised the GPU, and `--gpus N` makes bench.py a launcher chain (forbidden exec)
+case " $* " in *" --gpus "[2-9]*) echo "prof: profile one rank (--gpus 1)"; exit 2;; esac
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

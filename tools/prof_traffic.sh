@@ -2,6 +2,8 @@
 # usage (on the GPU box, from repo root): bash tools/prof_traffic.sh <tag> [bench args...]  -- kernel trace + FETCH_SIZE / WRITE_SIZE passes only
 set -o pipefail
 TAG=$1; shift
+# one process only: rocprofv3's preloaded runtime has initialised the GPU, and `--gpus N` makes bench.py a launcher chain (forbidden exec)
+case " $* " in *" --gpus "[2-9]*) echo "prof: profile one rank (--gpus 1)"; exit 2;; esac
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
