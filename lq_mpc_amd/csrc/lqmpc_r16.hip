@@ -65,16 +65,15 @@ static void launch_r16_one(const KParams &p, hipStream_t stream)
 #ifdef LQMPC_R16_PROF
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_r16_prof), sizeof z);
-        fprintf(stderr, "r16 prof (block %d ticks): chains %lld images+T %lld suffix/P %lld Fq %lld qr %lld invert %lld G/store %lld | rollout %lld\n",
-                PROFBLK, z[0], z[1], z[2], z[3], z[4], z[5], z[6], z[7]);
+        fprintf(stderr, "r16 prof (block %d ticks): set-up on the matrix core %lld v_r %lld | rollout %lld\n", PROFBLK, z[5], z[6], z[7]);
         fprintf(stderr, "r16 prof (grid): waves %lld  set-up %.0f  total %.0f ticks/wave | free wave-steps %lld at %.0f ticks | busy wave-steps %lld at %.0f ticks, "
                 "%.2f wave-iterations each (steps 1..T-1); %lld wave-iterations on the general (primal-capable) path in all\n", z[15], (double)z[13] / z[15], (double)z[14] / z[15], z[10], (double)z[8] / (z[10] ? z[10] : 1),
                 z[11], (double)z[9] / (z[11] ? z[11] : 1), (double)z[12] / (z[11] ? z[11] : 1), z[16]);
-        fprintf(stderr, "r16 prof (grid, ticks/wave): chains %.0f images+T %.0f suffix/P %.0f Fq %.0f qr %.0f invert %.0f G/store %.0f\n", (double)z[17] / z[15],
-                (double)z[18] / z[15], (double)z[19] / z[15], (double)z[20] / z[15], (double)z[21] / z[15], (double)z[22] / z[15], (double)z[23] / z[15]);
+        fprintf(stderr, "r16 prof (grid, ticks/wave): set-up on the matrix core %.0f v_r %.0f\n", (double)z[22] / z[15], (double)z[23] / z[15]);
         fprintf(stderr, "r16 prof (grid): %lld dual-only wave-iterations at %.0f ticks, %lld general at %.0f ticks\n", z[26], (double)z[24] / (z[26] ? z[26] : 1), z[16],
                 (double)z[25] / (z[16] ? z[16] : 1));
-        fprintf(stderr, "r16 prof (grid): step 0: %.0f ticks/wave, %.2f wave-iterations/wave, %.2f of them general\n", (double)z[27] / z[15], (double)z[28] / z[15], (double)z[29] / z[15]);
+        fprintf(stderr, "r16 prof (grid): step 0: %.0f ticks/wave, %.2f wave-iterations/wave, %.2f of them general; %lld of %lld wavefronts ever took the general (P-reading) path\n",
+                (double)z[27] / z[15], (double)z[28] / z[15], (double)z[29] / z[15], z[30], z[15]);
 #endif
     }
 }

@@ -233,7 +233,9 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     ldsd *L = (ldsd *)lds_raw + q * C::INST;
     ldsd *Pp = L + C::oP, *Wp = L + C::oW, *rL = L + C::oR, *xL = L + C::oX, *yL = L + C::oY;
     ldsi *list = (ldsi *)(L + C::oL);
+#ifdef LQMPC_R16_GJ_SETUP
     constexpr int DUMMY = C::oD - C::oP, DUMMYW = C::oD - C::oW;     // the dummy slot as an index into P / W
+#endif
     const long long Bsz = p.Bsz;
     const long long b_raw = slot0 + q;
     const bool valid = b_raw < slot_end;
@@ -286,7 +288,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             bg = p.perm ? (long long)p.perm[sl] : sl;
             Lg = (ldsd *)lds_raw + gq * C::INST;
         }
-        r16_setup_mfma<NX, NU, N, LPI, PACKED, RB>(p, bg, Lg, L, C::oP, C::oW, C::oG, C::oD, G);
+        r16_setup_mfma<NX, NU, N, LPI, PACKED, RB>(setup_args(p), bg, Lg, L, C::oW, C::oG, C::oD, G);
         RPROF(5);
         // constant part of the unconstrained minimiser: v_r = -W (2 gref + P centre) = -2 W gref - centre (references / off-centre boxes only)
         const bool has_lin = p.has_lin != 0;
@@ -648,6 +650,9 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     const bool writer = valid && i == 0;
     mask_t pL = 0, pU = 0;                  // active set of the previous step (row-uniform bit masks)
     int iters = 0, status = 0;
+#ifndef LQMPC_R16_GJ_SETUP
+    bool P_ready = false;                   // P is built the first time an iteration of this wavefront takes the primal side (r16_build_P)
+#endif
     // ---- one box QP at state x: v <- the optimum (my rows); updates the warm-start face, iters, status ----
     auto qp = [&](const double (&x)[NX], double (&v)[RB]) {
         double vu[RB];
@@ -694,6 +699,20 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                              max(__builtin_amdgcn_readlane(c, 32), __builtin_amdgcn_readlane(c, 48)));
                 else cw = __builtin_amdgcn_readfirstlane(c);
                 const bool any_primal = __ballot(busy && !dual) != 0ull;
+#ifndef LQMPC_R16_GJ_SETUP
+                if (any_primal && !P_ready) {                    // wave-uniform
+                    long long bg = bq;
+                    ldsd *Lg = L;
+                    if constexpr (LPI == 16) {
+                        const int gq = (lane >> 2) & 3;
+                        const long long sraw = slot0 + gq, sl = sraw < slot_end ? sraw : slot_end - 1;
+                        bg = p.perm ? (long long)p.perm[sl] : sl;
+                        Lg = (ldsd *)lds_raw + gq * C::INST;
+                    }
+                    r16_build_P<NX, NU, N, LPI, PACKED>(setup_args(p), bg, Lg, C::oP, C::oD);
+                    P_ready = true;
+                }
+#endif
                 if constexpr (LPI == 16) {
                     if (!any_primal) {
                         // ---- every busy instance of the wavefront is on the dual side: W_AA lam = r_A, v_F = v_unc,F - W_FA lam ----
@@ -1422,7 +1441,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #ifdef LQMPC_R16_PROF
         for (int k_ = 0; k_ < 5; ++k_) RPROF_ADD(8 + k_, prof_acc[k_]);
 #endif
-        RPROF_ADD(14, clock64() - prof_t0); RPROF_ADD(15, 1); RPROF_ADD(16, prof_slow);
+        RPROF_ADD(14, clock64() - prof_t0); RPROF_ADD(15, 1); RPROF_ADD(16, prof_slow); RPROF_ADD(30, prof_slow > 0 ? 1 : 0);
 #ifdef LQMPC_R16_PROF
         for (int k_ = 0; k_ < 8; ++k_) RPROF_ADD(17 + k_, prof_ph[k_]);
         RPROF_ADD(25, prof_slowt); RPROF_ADD(26, prof_fast);

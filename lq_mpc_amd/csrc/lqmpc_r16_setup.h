@@ -18,11 +18,12 @@
 //     Re_j = R + B'Sg_{j+1}B,  K_j = Re_j^-1 B'Sg_{j+1}A,  Acl_j = A - B K_j,  Sg_j = Q + A'Sg_{j+1}Acl_j,
 // the change of variables w_j = u_j + K_j x_j decouples the cost:  U'HU = sum_j w_j'Re_j w_j,  U = T w with T unit lower block
 // triangular,  T_kj = -rho_k(j) B,  rho_k(j) = K_k Acl_{k-1} .. Acl_{j+1}  (k > j).  Hence
-//     W = (2H)^-1 = 1/2 T D^-1 T' = sum_j T(:, j) (Re_j^-1 / 2) T(:, j)'       (one rank-NU update per stage, on 4x4 tiles),
+//     W = (2H)^-1 = 1/2 T D^-1 T' = sum_M T(:, M) (D_M^-1 / 2) T(:, M)'       (one update per column tile M of 4 / NU stages, on 4x4 tiles),
 //     G rows of stage k = -K_k Acl_{k-1} .. Acl_0 = -rho_k(-1)                    (what the rows rho_k have become after stage 0),
 // and the rows rho_k advance inside the same backward sweep (rho_k(j-1) = rho_k(j) Acl_j), so nothing is stored per stage.
 // P keeps its Lyapunov / Toeplitz form (round 2): block (bi, bj) = B' Lt_{bi+1} A^(bi-bj) B, Lt_N = P_T, Lt_k = Q + A'Lt_{k+1}A,
-// assembled tile by tile along the block diagonals so that the powers A^d B stream through one register.
+// assembled tile by tile along the block diagonals so that the powers A^d B stream through one register -- and only when a
+// wavefront first needs it (r16_build_P: the primal side of an iteration).
 #pragma once
 #include "lqmpc_wg_linalg.h"
 #include <utility>
@@ -74,55 +75,169 @@ __device__ __forceinline__ double small_inverse(double Re, int r, int c)
     }
 }
 
+// Zero-padded loads of one instance's model (instance-minor arrays or the probe's instance-major records) and of the shared weights
+// what the set-up reads of the kernel parameters, by value (a reference to KParams passed to the non-inlined r16_build_P would
+// make the whole block address-taken: every later p.xxx becomes a scratch load instead of a scalar load of the kernel argument)
+struct SetupArgs {
+    const double *rec, *A, *B, *sh;
+    long long Bsz;
+    int oQ, oP, oR;
+};
+__device__ __forceinline__ SetupArgs setup_args(const KParams &p) { return SetupArgs{p.rec, p.A, p.B, p.sh, p.Bsz, p.so.Q, p.so.P, p.so.R}; }
+
+template <int NX, int NU>
+struct ModelLd {
+    const SetupArgs &p;
+    long long bg;
+    static constexpr int REC = NX * NX + NX * NU + NX;
+    __device__ __forceinline__ double A(int a, int k) const
+    {
+        const bool v = a < NX && k < NX;
+        const int aa = v ? a : 0, kk = v ? k : 0;
+        const double x = p.rec ? p.rec[bg * REC + aa * NX + kk] : p.A[(long long)(aa * NX + kk) * p.Bsz + bg];
+        return v ? x : 0.0;
+    }
+    __device__ __forceinline__ double B(int a, int k) const
+    {
+        const bool v = a < NX && k >= 0 && k < NU;
+        const int aa = v ? a : 0, kk = v ? k : 0;
+        const double x = p.rec ? p.rec[bg * REC + NX * NX + aa * NU + kk] : p.B[(long long)(aa * NU + kk) * p.Bsz + bg];
+        return v ? x : 0.0;
+    }
+    __device__ __forceinline__ double S(int o, int a, int k, int dim) const
+    {
+        const bool v = a < dim && k < dim;
+        const double x = p.sh[o + (v ? a * dim + k : 0)];
+        return v ? x : 0.0;
+    }
+};
+
+// one 4x4 tile of a symmetric n x n matrix to LDS: lane (r, c) holds entry (4I + r, 4J + c); lower triangle only (packed), or both
+// triangles of full rows; predicated stores go to the dummy slot
+template <int n, bool PACKED>
+__device__ __forceinline__ void store_tile(wg::ldsd *M, int dummy, int I, int J, double val, bool on, int r, int c)
+{
+    constexpr int LDW = n + 1;
+    const int row = 4 * I + r, col = 4 * J + c;
+    const bool low = on && row < n && col <= row;
+    if constexpr (PACKED) M[low ? row * (row + 1) / 2 + col : dummy] = val;
+    else {
+        M[low ? row * LDW + col : dummy] = val;
+        M[(low && col < row) ? col * LDW + row : dummy] = val;
+    }
+}
+
+// P = 2 (H + Rbar) of one instance to LDS, in its Lyapunov / Toeplitz form: tile (I, I - D) = sum_p (Lt_{k+1} B placed at stage k's
+// columns)' [A^(D SPT + p) B | A^(D SPT + p - 1) B | ..],  k = I SPT + p.  Only the primal side of an active-set iteration reads P
+// (|A| > n / 2), so the kernels call this the first time a wavefront gets there (a quarter of the wavefronts of C3's default mix,
+// one in a hundred of C4's) instead of in every set-up.  Ends with a barrier.  NOT inlined: inside the iteration loop its ~80 live
+// registers would be charged to every iteration (the sweep / C4 builds spill); as a call its frame costs only where it runs.
+template <int NX, int NU, int N, int LPI, bool PACKED>
+__device__ __attribute__((noinline)) void r16_build_P(const SetupArgs p, long long bg, wg::ldsd *Lg, int oP, int oD)
+{
+    using T = SetupT<NX, NU, N, LPI>;
+    constexpr int n = T::n, NT = T::NT, SPT = T::SPT, NTM = T::NTM;
+    const int lane = threadIdx.x, r = lane >> 4, c = lane & 3, g = (lane >> 2) & 3;
+    const double *sh = p.sh;
+    wg::ldsd *Pp = Lg + oP;
+    const int dP = oD - oP;
+    const ModelLd<NX, NU> ld{p, bg};
+    const double A = ld.A(r, c), At = ld.A(c, r), Q = ld.S(p.oQ, r, c, NX), PT = ld.S(p.oP, r, c, NX);
+    double Bpl[SPT];                                                  // B in column block q of a tile
+#pragma unroll
+    for (int qq = 0; qq < SPT; ++qq) Bpl[qq] = ld.B(r, c - qq * NU);
+    double ap[NTM][SPT];                                              // a-operands of my tiles' stages
+#pragma unroll
+    for (int m = 0; m < NTM; ++m)
+#pragma unroll
+        for (int pp = 0; pp < SPT; ++pp) ap[m][pp] = 0.0;
+    double Lt = PT;
+    sfor<0, N>([&](auto kc) {
+        constexpr int k = N - 1 - decltype(kc)::value;
+        constexpr int I = k / SPT, pp = k % SPT;
+        const double v = mm4(Lt, Bpl[pp]);
+        if constexpr (LPI == 16) ap[I][pp] = v;
+        else ap[I / 4][pp] = (g == I % 4) ? v : ap[I / 4][pp];
+        if constexpr (k > 0) Lt = mm4(A, mm4(Lt, A), Q);
+    });
+    double Rd = 0.0;                                                  // R on the diagonal blocks of a diagonal tile
+#pragma unroll
+    for (int qq = 0; qq < SPT; ++qq) {
+        const int rr = r - qq * NU, cc = c - qq * NU;
+        const bool v = rr >= 0 && rr < NU && cc >= 0 && cc < NU;
+        const double x = sh[p.oR + (v ? rr * NU + cc : 0)];
+        Rd = v ? x : Rd;
+    }
+    double X = Bpl[0];                                                // X_d = [A^d B | A^(d-1) B | ..] (columns of negative powers: zero)
+    sfor<0, NT>([&](auto Dc) {
+        constexpr int D = decltype(Dc)::value;
+        double acc[NTM];
+#pragma unroll
+        for (int m = 0; m < NTM; ++m) acc[m] = (D == 0) ? Rd : 0.0;
+        sfor<0, SPT>([&](auto pc) {
+            constexpr int pp = decltype(pc)::value;
+            constexpr int d = D * SPT + pp;
+            if constexpr (d > 0) X = mm4(At, X, d <= SPT - 1 ? Bpl[d <= SPT - 1 ? d : 0] : 0.0);
+            if constexpr (LPI == 16) {
+                sfor<D, NT>([&](auto Ic) { constexpr int I = decltype(Ic)::value; acc[I] = mm4(ap[I][pp], X, acc[I]); });
+            } else {
+                sfor<D / 4, NTM>([&](auto mc) { constexpr int m = decltype(mc)::value; acc[m] = mm4(ap[m][pp], X, acc[m]); });
+            }
+        });
+        if constexpr (LPI == 16) {
+            sfor<D, NT>([&](auto Ic) { constexpr int I = decltype(Ic)::value; store_tile<n, PACKED>(Pp, dP, I, I - D, 2.0 * acc[I], true, r, c); });
+        } else {
+            sfor<D / 4, NTM>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                const int I = 4 * m + g;
+                store_tile<n, PACKED>(Pp, dP, I, I - D, 2.0 * acc[m], I >= D && I < NT, r, c);
+            });
+        }
+    });
+    __syncthreads();
+}
+
 // The set-up.  Lg: LDS of block g's instance (LPI = 16) or of the one instance (LPI = 64); oP / oW: where P and W go in it (packed
 // lower triangle: index row (row + 1) / 2 + col; or full rows of stride n + 1, both triangles); oG: n NX doubles of scratch for G
 // (may alias P / W: they are written after G has been read back); oD: a dummy slot for predicated stores.
 // bg: the instance block g works on.  Lq / valid rows: where the lane's OWN instance (q = lane / LPI) reads its rows of G back.
-// On return: P, W in LDS (a barrier has been passed), G[s][a] = row (i + LPI s) of G in registers.
+// On return: W in LDS (a barrier has been passed), G[s][a] = row (i + LPI s) of G in registers.  P: r16_build_P, on demand.
 template <int NX, int NU, int N, int LPI, bool PACKED, int RB>
-__device__ __forceinline__ void r16_setup_mfma(const KParams &p, long long bg, wg::ldsd *Lg, wg::ldsd *Lq, int oP, int oW, int oG, int oD,
+__device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg, wg::ldsd *Lg, wg::ldsd *Lq, int oW, int oG, int oD,
                                               double (&G)[RB][NX])
 {
     using T = SetupT<NX, NU, N, LPI>;
-    constexpr int n = T::n, NT = T::NT, SPT = T::SPT, NTM = T::NTM, LDW = n + 1;
-    constexpr int REC = NX * NX + NX * NU + NX;
+    constexpr int n = T::n, NT = T::NT, SPT = T::SPT, NTM = T::NTM;
     const int lane = threadIdx.x, r = lane >> 4, c = lane & 3, g = (lane >> 2) & 3;
-    const long long Bsz = p.Bsz;
-    const double *sh = p.sh;
-    wg::ldsd *Pp = Lg + oP, *Wp = Lg + oW, *Gs = Lg + oG;
-    const int dP = oD - oP, dW = oD - oW, dG = oD - oG;
+    wg::ldsd *Wp = Lg + oW, *Gs = Lg + oG;
+    const int dW = oD - oW, dG = oD - oG;
     // ---- the model and the weights as register matrices ----
-    auto ldA = [&](int a, int k) -> double {
-        const bool v = a < NX && k < NX;
-        const int aa = v ? a : 0, kk = v ? k : 0;
-        const double x = p.rec ? p.rec[bg * REC + aa * NX + kk] : p.A[(long long)(aa * NX + kk) * Bsz + bg];
-        return v ? x : 0.0;
-    };
-    auto ldB = [&](int a, int k) -> double {
-        const bool v = a < NX && k >= 0 && k < NU;
-        const int aa = v ? a : 0, kk = v ? k : 0;
-        const double x = p.rec ? p.rec[bg * REC + NX * NX + aa * NU + kk] : p.B[(long long)(aa * NU + kk) * Bsz + bg];
-        return v ? x : 0.0;
-    };
-    auto ldS = [&](int o, int a, int k, int dim) -> double {
-        const bool v = a < dim && k < dim;
-        const double x = sh[o + (v ? a * dim + k : 0)];
-        return v ? x : 0.0;
-    };
-    const double A = ldA(r, c), At = ldA(c, r), Bp = ldB(r, c), Bt = ldB(c, r);
-    const double Q = ldS(p.so.Q, r, c, NX), PT = ldS(p.so.P, r, c, NX), Rp = ldS(p.so.R, r, c, NU);
-    const double nBp = -Bp, nBt = -Bt;
+    const ModelLd<NX, NU> ld{p, bg};
+    auto ldA = [&](int a, int k) -> double { return ld.A(a, k); };
+    auto ldB = [&](int a, int k) -> double { return ld.B(a, k); };
+    auto ldS = [&](int o, int a, int k, int dim) -> double { return ld.S(o, a, k, dim); };
+    const double A = ldA(r, c), Bp = ldB(r, c), Bt = ldB(c, r);
+    const double Q = ldS(p.oQ, r, c, NX), PT = ldS(p.oP, r, c, NX), Rp = ldS(p.oR, r, c, NU);
+    const double nBt = -Bt;
 
-    // ---- backward sweep: Riccati recursion, the rows rho_k, W by rank-NU updates ----
+    // ---- backward sweep: Riccati recursion, the rows rho_k, W by one update per column tile ----
     double Wacc[NTM][NT];                         // tile (I, J), J <= I: LPI = 16: Wacc[I][J]; LPI = 64: block g of Wacc[m][J] holds tile (4m+g, J)
     double rho[NTM];                              // rho' of the rows of tile I (NX x 4: column = row of the tile)
     double rho_r[(LPI == 64) ? NT : 1];           // LPI = 64: every tile's rho' in every block (the B operand of an update is one tile for all)
+    // T(:, M)' and (T(:, M) D_M^-1 / 2)' of the current column tile M on the rows of every tile from M on: register-matrix row
+    // q NU + u <-> column u of stage M SPT + q; filled stage by stage (the accumulator operand), used once per column tile
+    double TtA[NT], TDA[NTM];
+    double Bpl[SPT], nBpl[SPT];                   // B (and -B) in column block q of a tile
+#pragma unroll
+    for (int qq = 0; qq < SPT; ++qq) { Bpl[qq] = ldB(r, c - qq * NU); nBpl[qq] = -Bpl[qq]; }
 #pragma unroll
     for (int m = 0; m < NTM; ++m) {
-        rho[m] = 0.0;
+        rho[m] = 0.0; TDA[m] = 0.0;
 #pragma unroll
         for (int J = 0; J < NT; ++J) Wacc[m][J] = 0.0;
     }
+#pragma unroll
+    for (int J = 0; J < NT; ++J) TtA[J] = 0.0;
     if constexpr (LPI == 64) {
 #pragma unroll
         for (int J = 0; J < NT; ++J) rho_r[J] = 0.0;
@@ -130,7 +245,8 @@ __device__ __forceinline__ void r16_setup_mfma(const KParams &p, long long bg, w
     double S = PT;
     sfor<0, N>([&](auto jc) {
         constexpr int j = N - 1 - decltype(jc)::value;
-        constexpr int Ij = T::tile_of_stage(j), off = T::off_of_stage(j);
+        constexpr int Ij = T::tile_of_stage(j), off = T::off_of_stage(j), q = off / NU;
+        constexpr bool first_of_tile = (j == N - 1) || (q == SPT - 1);        // (backward: the highest stage of column tile Ij comes first)
         const double SA = mm4(S, A), SB = mm4(S, Bp);
         const double F = mm4(Bp, SA), Re = mm4(Bp, SB, Rp);
         const double R0 = small_inverse<NU>(Re, r, c);
@@ -140,33 +256,30 @@ __device__ __forceinline__ void r16_setup_mfma(const KParams &p, long long bg, w
             const double Z = mm4(S, Acl);
             S = mm4(A, Z, Q);
         }
-        const double SH = (r < NU && c == off + r) ? 1.0 : 0.0;       // the identity block of T(:, j) at the tile position of stage j; as a right factor: moves columns 0.. to off..
+        const double SH = (r < NU && c == off + r) ? 1.0 : 0.0;       // as a right factor: moves columns 0.. to off..; its transpose as a left factor: rows
+        const double Iq = (r == c && r >= off && r < off + NU) ? 1.0 : 0.0;   // the identity block of T(:, j), at the tile position of stage j
         const double R0h = 0.5 * R0;
-        const double nBRt = mm4(nBt, R0h);                            // -(1/2) B Re^-1
         const double Ktp = mm4(K, SH);                                // K' in the columns of stage j
-        const double R1h = (off == 0) ? R0h : mm4(R0h, SH);           // Re^-1 / 2 in the columns of stage j
-        // T(:, j)' and (T(:, j) Re^-1 / 2)' on the rows of every tile from I_j on (rows of these register matrices: the NU columns of block j)
-        double Tt[NT], TDt[NTM];
-        sfor<Ij, NT>([&](auto Jc) {
-            constexpr int J = decltype(Jc)::value;
-            if constexpr (T::live(J, j)) {
-                if constexpr (LPI == 64) Tt[J] = mm4(nBp, rho_r[J < NT && LPI == 64 ? J : 0], J == Ij ? SH : 0.0);
-                else Tt[J] = mm4(nBp, rho[LPI == 16 ? J : 0], J == Ij ? SH : 0.0);
-            } else Tt[J] = SH;                                        // (J == Ij and no row of a later stage in the tile yet)
-        });
+        const double R1h = (off == 0) ? R0h : mm4(R0h, SH);           // Re^-1 / 2, columns moved to stage j's
+        const double Rqq = (off == 0) ? R0h : mm4(SH, R1h);           // ... and rows
+        const double nBRt = mm4(nBt, R1h);                            // -(1/2) B Re^-1 in the columns of stage j
         if constexpr (LPI == 16) {
             sfor<Ij, NT>([&](auto Ic) {
                 constexpr int I = decltype(Ic)::value;
-                if constexpr (T::live(I, j)) TDt[I] = mm4(nBRt, rho[I], I == Ij ? R1h : 0.0);
-                else TDt[I] = R1h;
+                const double cT = (first_of_tile ? 0.0 : TtA[I]) + (I == Ij ? Iq : 0.0);
+                const double cD = (first_of_tile ? 0.0 : TDA[I]) + (I == Ij ? Rqq : 0.0);
+                if constexpr (T::live(I, j)) { TtA[I] = mm4(nBpl[q], rho[I], cT); TDA[I] = mm4(nBRt, rho[I], cD); }
+                else { TtA[I] = cT; TDA[I] = cD; }                  // (I == Ij and no row of a later stage in the tile yet)
             });
-            sfor<Ij, NT>([&](auto Ic) {
-                constexpr int I = decltype(Ic)::value;
-                sfor<Ij, I + 1>([&](auto Jc) {
-                    constexpr int J = decltype(Jc)::value;
-                    Wacc[I][J] = mm4(TDt[I], Tt[J], Wacc[I][J]);
+            if constexpr (q == 0) {
+                sfor<Ij, NT>([&](auto Ic) {
+                    constexpr int I = decltype(Ic)::value;
+                    sfor<Ij, I + 1>([&](auto Jc) {
+                        constexpr int J = decltype(Jc)::value;
+                        Wacc[I][J] = mm4(TDA[I], TtA[J], Wacc[I][J]);
+                    });
                 });
-            });
+            }
             sfor<Ij, NT>([&](auto Ic) {
                 constexpr int I = decltype(Ic)::value;
                 if constexpr (T::live(I, j)) rho[I] = mm4(Acl, rho[I], I == Ij ? Ktp : 0.0);
@@ -174,18 +287,26 @@ __device__ __forceinline__ void r16_setup_mfma(const KParams &p, long long bg, w
             });
         } else {
             constexpr int m0 = Ij / 4;
+            sfor<Ij, NT>([&](auto Jc) {
+                constexpr int J = decltype(Jc)::value;
+                const double cT = (first_of_tile ? 0.0 : TtA[J]) + (J == Ij ? Iq : 0.0);
+                if constexpr (T::live(J, j)) TtA[J] = mm4(nBpl[q], rho_r[J], cT);
+                else TtA[J] = cT;
+            });
             sfor<m0, NTM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 const bool mine = (4 * m + g == Ij);
-                TDt[m] = mm4(nBRt, rho[m], mine ? R1h : 0.0);
+                TDA[m] = mm4(nBRt, rho[m], (first_of_tile ? 0.0 : TDA[m]) + (mine ? Rqq : 0.0));
             });
-            sfor<Ij, NT>([&](auto Jc) {
-                constexpr int J = decltype(Jc)::value;
-                sfor<J / 4, NTM>([&](auto mc) {
-                    constexpr int m = decltype(mc)::value;
-                    Wacc[m][J] = mm4(TDt[m], Tt[J], Wacc[m][J]);      // (blocks whose tile 4m+g < J compute an upper-triangle tile: never stored)
+            if constexpr (q == 0) {
+                sfor<Ij, NT>([&](auto Jc) {
+                    constexpr int J = decltype(Jc)::value;
+                    sfor<J / 4, NTM>([&](auto mc) {
+                        constexpr int m = decltype(mc)::value;
+                        Wacc[m][J] = mm4(TDA[m], TtA[J], Wacc[m][J]);     // (blocks whose tile 4m+g < J compute an upper-triangle tile: never stored)
+                    });
                 });
-            });
+            }
             sfor<m0, NTM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 const bool mine = (4 * m + g == Ij);
@@ -223,77 +344,13 @@ __device__ __forceinline__ void r16_setup_mfma(const KParams &p, long long bg, w
     __syncthreads();
 
     // ---- W to LDS ----
-    auto store_tile = [&](wg::ldsd *M, int dummy, int I, int J, double val, bool on) {
-        const int row = 4 * I + r, col = 4 * J + c;
-        const bool low = on && row < n && col <= row;
-        if constexpr (PACKED) M[low ? row * (row + 1) / 2 + col : dummy] = val;
-        else {
-            M[low ? row * LDW + col : dummy] = val;
-            M[(low && col < row) ? col * LDW + row : dummy] = val;
-        }
-    };
 #pragma unroll
     for (int m = 0; m < NTM; ++m)
 #pragma unroll
         for (int J = 0; J < NT; ++J) {
             const int I = (LPI == 16) ? m : 4 * m + g;
-            if ((LPI == 16) ? (J <= m) : (J <= 4 * m + 3)) store_tile(Wp, dW, I, J, Wacc[m][J], I < NT && J <= I);
+            if ((LPI == 16) ? (J <= m) : (J <= 4 * m + 3)) store_tile<n, PACKED>(Wp, dW, I, J, Wacc[m][J], I < NT && J <= I, r, c);
         }
-
-    // ---- P = 2 (H + Rbar): tile (I, I - D) = sum_p (Lt_{k+1} B placed at stage k's columns)' [A^(D SPT + p) B | A^(D SPT + p - 1) B | ..],  k = I SPT + p ----
-    {
-        double ap[NTM][SPT];                                          // a-operands of my tiles' stages
-        double Bpl[SPT];                                              // B in column block q of a tile
-#pragma unroll
-        for (int qq = 0; qq < SPT; ++qq) Bpl[qq] = ldB(r, c - qq * NU);
-#pragma unroll
-        for (int m = 0; m < NTM; ++m)
-#pragma unroll
-            for (int pp = 0; pp < SPT; ++pp) ap[m][pp] = 0.0;
-        double Lt = PT;
-        sfor<0, N>([&](auto kc) {
-            constexpr int k = N - 1 - decltype(kc)::value;
-            constexpr int I = k / SPT, pp = k % SPT;
-            const double v = mm4(Lt, Bpl[pp]);
-            if constexpr (LPI == 16) ap[I][pp] = v;
-            else ap[I / 4][pp] = (g == I % 4) ? v : ap[I / 4][pp];
-            if constexpr (k > 0) Lt = mm4(A, mm4(Lt, A), Q);
-        });
-        double Rd = 0.0;                                              // R on the diagonal blocks of a diagonal tile
-#pragma unroll
-        for (int qq = 0; qq < SPT; ++qq) {
-            const int rr = r - qq * NU, cc = c - qq * NU;
-            const bool v = rr >= 0 && rr < NU && cc >= 0 && cc < NU;
-            const double x = sh[p.so.R + (v ? rr * NU + cc : 0)];
-            Rd = v ? x : Rd;
-        }
-        double X = Bpl[0];                                            // X_d = [A^d B | A^(d-1) B | ..] (columns of negative powers: zero)
-        sfor<0, NT>([&](auto Dc) {
-            constexpr int D = decltype(Dc)::value;
-            double acc[NTM];
-#pragma unroll
-            for (int m = 0; m < NTM; ++m) acc[m] = (D == 0) ? Rd : 0.0;
-            sfor<0, SPT>([&](auto pc) {
-                constexpr int pp = decltype(pc)::value;
-                constexpr int d = D * SPT + pp;
-                if constexpr (d > 0) X = mm4(At, X, d <= SPT - 1 ? Bpl[d <= SPT - 1 ? d : 0] : 0.0);
-                if constexpr (LPI == 16) {
-                    sfor<D, NT>([&](auto Ic) { constexpr int I = decltype(Ic)::value; acc[I] = mm4(ap[I][pp], X, acc[I]); });
-                } else {
-                    sfor<D / 4, NTM>([&](auto mc) { constexpr int m = decltype(mc)::value; acc[m] = mm4(ap[m][pp], X, acc[m]); });
-                }
-            });
-            if constexpr (LPI == 16) {
-                sfor<D, NT>([&](auto Ic) { constexpr int I = decltype(Ic)::value; store_tile(Pp, dP, I, I - D, 2.0 * acc[I], true); });
-            } else {
-                sfor<D / 4, NTM>([&](auto mc) {
-                    constexpr int m = decltype(mc)::value;
-                    const int I = 4 * m + g;
-                    store_tile(Pp, dP, I, I - D, 2.0 * acc[m], I >= D && I < NT);
-                });
-            }
-        });
-    }
     __syncthreads();
 }
 
