@@ -118,6 +118,10 @@ typedef struct lqmpc_options {
                           two-waves throughput build above), 0 throughput build, 1 latency build.  (default -1) */
     int32_t nwide;      /* packed family, sorted rollouts: how many of the hardest instances get the 16-lane-row layout in
                           the two-tier launch; -1 auto (min(Bsz/8, 4096)), 0 none.  (default -1) */
+    int32_t jit;        /* shapes (nx, nu, N) without a prebuilt instantiation: compile the 16-lane-row kernel for them at run time
+                          (hiprtc; nx <= 8, nu <= 4, N*nu <= 48; about two seconds per shape and entry point on first use, then
+                          cached) instead of falling back to the generic kernel.  -1 auto (= on), 0 off, 1 on.  (default -1) */
+    int32_t reserved2;  /* 0 */
 } lqmpc_options;
 
 /* Limits of this build. */
@@ -141,6 +145,13 @@ int lqmpc_sync(lqmpc_handle *h);
 void lqmpc_default_options(lqmpc_options *opt);
 int lqmpc_set_options(lqmpc_handle *h, const lqmpc_options *opt);
 int lqmpc_get_options(const lqmpc_handle *h, lqmpc_options *opt);
+
+/* Run-time compiled kernels (options.jit).  lqmpc_jit_cache_dir: directory where code objects are kept across processes (NULL or
+ * "" = in memory only; process-wide).  lqmpc_jit_compile: compile (or find in that directory) every kernel of one shape now -- it needs
+ * no GPU, so a build machine can fill the cache; returns the number of code objects available (5) or a negative lqmpc_error, with the
+ * compiler's message in `log` if given. */
+int lqmpc_jit_cache_dir(const char *dir);
+int lqmpc_jit_compile(int nx, int nu, int N, char *log, int log_len);
 
 /* 1 if a register-resident specialisation for (nx,nu,N) is compiled in, else 0. */
 int lqmpc_has_specialization(int nx, int nu, int N);

@@ -9,6 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblqmpc_hip.so")
+JIT_CACHE = os.path.join(_HERE, "_jit_cache")
 CSRC = os.path.join(_HERE, "csrc")
 
 _D = ctypes.POINTER(ctypes.c_double)
@@ -27,6 +28,7 @@ EXPORTS = [
     "lqmpc_sweep_batch", "lqmpc_sweep_batch_dev",
     "lqmpc_bounds_batch", "lqmpc_bounds_batch_dev",
     "lqmpc_timer_begin", "lqmpc_timer_end",
+    "lqmpc_jit_cache_dir", "lqmpc_jit_compile",
 ]
 
 
@@ -35,7 +37,7 @@ class Options(ctypes.Structure):
                 ("max_iter", ctypes.c_int32), ("polish", ctypes.c_int32), ("kernel", ctypes.c_int32),
                 ("presolve", ctypes.c_int32), ("order", ctypes.c_int32), ("warm_start", ctypes.c_int32),
                 ("layout", ctypes.c_int32), ("r16_maxit", ctypes.c_int32), ("r16_build", ctypes.c_int32),
-                ("nwide", ctypes.c_int32)]
+                ("nwide", ctypes.c_int32), ("jit", ctypes.c_int32), ("reserved2", ctypes.c_int32)]
 
 
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_SPECIALIZED, KERNEL_WORKGROUP = 0, 1, 2, 3
@@ -98,8 +100,21 @@ def lib():
     L.lqmpc_bounds_batch_dev.argtypes = bounds_args
     L.lqmpc_timer_begin.argtypes = [_H]
     L.lqmpc_timer_end.argtypes = [_H, ctypes.POINTER(ctypes.c_float)]
+    L.lqmpc_jit_cache_dir.argtypes = [ctypes.c_char_p]
+    L.lqmpc_jit_compile.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+    # code objects of run-time compiled shapes are kept next to the library (falls back to memory only if not writable)
+    L.lqmpc_jit_cache_dir(JIT_CACHE.encode())
     _lib = L
     return L
+
+
+def jit_compile(nx, nu, N):
+    """Compile (or find in the cache) every kernel of one shape now; needs no GPU.  Returns the number of code objects."""
+    log = ctypes.create_string_buffer(4096)
+    rc = lib().lqmpc_jit_compile(int(nx), int(nu), int(N), log, len(log))
+    if rc < 0:
+        raise LqmpcError(f"lqmpc_jit_compile({nx},{nu},{N}) -> {rc}: {log.value.decode(errors='replace')}")
+    return rc
 
 
 def check(rc):

@@ -28,6 +28,12 @@ bool launch_r16(const KParams &p, hipStream_t stream, const char **name);
 // lqmpc_wg.hip: one instance per workgroup, 32 < n <= 128
 bool wg_supported(const KParams &p, const double *lb, const double *ub);
 bool launch_wg(const KParams &p, hipStream_t stream, const char **name);
+// lqmpc_jit.hip: the 16-lane-row kernel (and the probe) of a shape without a prebuilt instantiation, compiled at run time
+bool jit_r16_shape(int nx, int nu, int N, int *lpi);
+bool jit_available(int device, int nx, int nu, int N, int mode, std::string *why);
+bool launch_jit(int device, const KParams &p, hipStream_t stream, const char **name, std::string *why);
+// lqmpc_generic.hip: the generic kernel over a device-side list (p.perm, p.count_dev) with `cols` workspace columns
+void launch_generic_list(const KParams &p, int cols, hipStream_t stream);
 }  // namespace lqmpc
 
 using lqmpc::KParams;
@@ -80,7 +86,10 @@ struct lqmpc_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const char *last_kernel = "none";
     bool use_wg = false;             // set by prepare(): this call runs on the workgroup kernel
+    bool use_jit = false;            // set by prepare(): this call runs on a run-time compiled 16-lane-row kernel (lqmpc_jit.hip)
 };
+
+constexpr int JIT_FALLBACK_COLS = 1024;   // workspace columns of the generic kernel when it only serves a hand-back list
 
 constexpr size_t HIST_INTS = (size_t)lqmpc::ORDER_CELLS * lqmpc::ORDER_PAD;
 constexpr size_t FAIL_HDR = 16 + 2 * HIST_INTS;    // ints in front of the hand-back list: its count, the order's two alternating sets of counters
@@ -159,6 +168,8 @@ void lqmpc_default_options(lqmpc_options *opt)
     opt->r16_maxit = 12;
     opt->r16_build = -1;
     opt->nwide = -1;
+    opt->jit = -1;
+    opt->reserved2 = 0;
 }
 
 int lqmpc_create_on_stream(int device, void *hip_stream, lqmpc_handle **out)
@@ -239,6 +250,7 @@ int lqmpc_set_options(lqmpc_handle *h, const lqmpc_options *opt)
     if (opt->r16_maxit < 0 || opt->r16_maxit > 64) return fail(LQMPC_ERR_BAD_ARG, "r16_maxit must be in [0,64]");
     if (opt->r16_build < -1 || opt->r16_build > 1) return fail(LQMPC_ERR_BAD_ARG, "r16_build must be -1, 0 or 1");
     if (opt->nwide < -1) return fail(LQMPC_ERR_BAD_ARG, "nwide must be -1 (auto) or a count");
+    if (opt->jit < -1 || opt->jit > 1) return fail(LQMPC_ERR_BAD_ARG, "jit must be -1, 0 or 1");
     h->opt = *opt;
     return 0;
 }
@@ -398,11 +410,27 @@ static int prepare(lqmpc_handle *h, const Call &c, KParams &p)
     p.r16_build = h->opt.r16_build;
     if (h->opt.kernel == LQMPC_KERNEL_SPECIALIZED && !lqmpc::spec_available(nx, nu, N))
         return fail(LQMPC_ERR_UNSUPPORTED, "no register-resident specialisation built for these dims");
-    h->use_wg = !use_spec(h, nx, nu, N) && (h->opt.kernel == LQMPC_KERNEL_AUTO || h->opt.kernel == LQMPC_KERNEL_WORKGROUP) &&
+    // a shape without a prebuilt instantiation inside the 16-lane-row domain: compile its kernel now (first use: ~2 s; then cached).
+    // The algorithm is the presolve + warm-started active set, so the option combinations that switch those off stay on the
+    // generic / workgroup kernels, as do the shapes whose compile fails (no hiprtc on the machine: reported by last_error once).
+    h->use_jit = false;
+    if (h->opt.kernel == LQMPC_KERNEL_AUTO && h->opt.jit != 0 && !lqmpc::spec_available(nx, nu, N) && p.presolve && p.warm_start &&
+        c.Bsz <= INT32_MAX && lqmpc::jit_r16_shape(nx, nu, N, nullptr)) {
+        std::string why;
+        h->use_jit = lqmpc::jit_available(h->device, nx, nu, N, c.mode, &why);
+        if (!h->use_jit) g_err = "run-time compile unavailable, using the generic kernels: " + why;
+    }
+    h->use_wg = !use_spec(h, nx, nu, N) && !h->use_jit && (h->opt.kernel == LQMPC_KERNEL_AUTO || h->opt.kernel == LQMPC_KERNEL_WORKGROUP) &&
                 lqmpc::wg_supported(p, c.lb, c.ub);
     if (h->opt.kernel == LQMPC_KERNEL_WORKGROUP && !h->use_wg)
         return fail(LQMPC_ERR_UNSUPPORTED, "the workgroup kernel needs 32 < N*nu <= 128, nx <= 16, nu <= 8 and an LDS image within 160 KiB");
-    if (!use_spec(h, nx, nu, N) && !h->use_wg) {
+    if (h->use_jit) {
+        // the generic kernel only ever sees the instances the 16-lane-row kernel hands back: a bounded workspace, walked by a grid-stride loop
+        p.ws_stride = JIT_FALLBACK_COLS;
+        rc = ensure(h, h->ws, (size_t)lqmpc::generic_ws_entries(nx, nu, N) * (size_t)p.ws_stride * sizeof(double));
+        if (rc) return rc;
+        p.ws = (double *)h->ws.p;
+    } else if (!use_spec(h, nx, nu, N) && !h->use_wg) {
         p.ws_stride = (c.Bsz + 63) / 64 * 64;
         const size_t bytes = (size_t)lqmpc::generic_ws_entries(nx, nu, N) * (size_t)p.ws_stride * sizeof(double);
         rc = ensure(h, h->ws, bytes);
@@ -446,7 +474,10 @@ static int build_order(lqmpc_handle *h, KParams &p)
     q.fail_count = (int *)h->fail.p;
     q.stage = (double *)h->rec.p;
     const char *name = nullptr;
-    if (!lqmpc::launch_spec(q, h->stream, &name)) return fail(LQMPC_ERR_UNSUPPORTED, "probe launch failed");
+    if (h->use_jit) {
+        std::string why;
+        if (!lqmpc::launch_jit(h->device, q, h->stream, &name, &why)) return fail(LQMPC_ERR_UNSUPPORTED, "probe launch failed: " + why);
+    } else if (!lqmpc::launch_spec(q, h->stream, &name)) return fail(LQMPC_ERR_UNSUPPORTED, "probe launch failed");
     lqmpc::launch_order_scatter(q, (int *)h->perm.p, h->stream);
     HIP_TRY(hipGetLastError());
     h->hist_turn ^= 1;
@@ -514,11 +545,19 @@ static int launch_r16_with_hand_back(lqmpc_handle *h, KParams &p)
     int rc = prepare_hand_back(h, p);
     if (rc) return rc;
     const char *name = nullptr;
-    if (!lqmpc::launch_r16(p, h->stream, &name)) return fail(LQMPC_ERR_UNSUPPORTED, "r16 launch failed");
+    if (h->use_jit) {
+        std::string why;
+        if (!lqmpc::launch_jit(h->device, p, h->stream, &name, &why)) return fail(LQMPC_ERR_HIP, "run-time compiled kernel: " + why);
+    } else if (!lqmpc::launch_r16(p, h->stream, &name)) return fail(LQMPC_ERR_UNSUPPORTED, "r16 launch failed");
     HIP_TRY(hipGetLastError());
     KParams f = p;
     f.perm = p.fail_list; f.count_dev = p.fail_count; f.fail_list = nullptr; f.fail_count = nullptr; f.nwide = 0;
     const char *name2 = nullptr;
+    // second pass over the hand-back list: the packed kernel (interior point + polish) where the shape has one, the generic kernel otherwise
+    auto second = [&](const KParams &g) -> bool {
+        if (h->use_jit) { lqmpc::launch_generic_list(g, JIT_FALLBACK_COLS, h->stream); return true; }
+        return lqmpc::launch_spec(g, h->stream, &name2);
+    };
     if (p.mode == lqmpc::MODE_SWEEP) {         // the packed kernel has no fused mode: max V_N, then the rollout, over the list
         // the two passes write status / iters of the listed instances: the max-V_N pass into side buffers, merged below
         // (status = the worse of the two parts, iters = their sum -- the contract of lqmpc_sweep_batch, as on the two-launch path)
@@ -527,11 +566,11 @@ static int launch_r16_with_hand_back(lqmpc_handle *h, KParams &p)
         f.mode = lqmpc::MODE_MAXVN;
         f.status = p.status ? (int *)h->st2.p : nullptr;
         f.iters = p.iters ? (int *)h->it2.p : nullptr;
-        if (!lqmpc::launch_spec(f, h->stream, &name2)) return fail(LQMPC_ERR_UNSUPPORTED, "hand-back launch failed");
+        if (!second(f)) return fail(LQMPC_ERR_UNSUPPORTED, "hand-back launch failed");
         f.mode = lqmpc::MODE_ROLLOUT;
         f.status = p.status; f.iters = p.iters;
     }
-    if (!lqmpc::launch_spec(f, h->stream, &name2)) return fail(LQMPC_ERR_UNSUPPORTED, "hand-back launch failed");
+    if (!second(f)) return fail(LQMPC_ERR_UNSUPPORTED, "hand-back launch failed");
     HIP_TRY(hipGetLastError());
     if (p.mode == lqmpc::MODE_SWEEP && (p.status || p.iters)) {
         const unsigned blocks = (unsigned)(p.Bsz < 65536 ? (p.Bsz + 255) / 256 : 256);
@@ -580,7 +619,7 @@ int lqmpc_solve_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, c
     int rc = prepare(h, c, p);
     if (rc) return rc;
     p.A = dA; p.B = dB; p.x0 = dx0; p.u0 = du0; p.VN = dVN; p.status = dstatus; p.iters = diters;
-    if (use_spec(h, nx, nu, N) && use_r16(h, p, Bsz, INT32_MAX)) return launch_r16_with_hand_back(h, p);
+    if (h->use_jit || (use_spec(h, nx, nu, N) && use_r16(h, p, Bsz, INT32_MAX))) return launch_r16_with_hand_back(h, p);
     return launch(h, p);
 }
 
@@ -601,7 +640,7 @@ int lqmpc_rollout_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz,
     if (true_per_instance) { p.At = A_true; p.Bt = B_true; }
     const bool spec = use_spec(h, nx, nu, N);
     const int order = h->opt.order < 0 ? ((spec && p.presolve && T >= 4 && Bsz >= 1024) ? 1 : 0) : (spec ? h->opt.order : 0);
-    if (spec && use_r16(h, p, Bsz, INT32_MAX)) {
+    if (h->use_jit || (spec && use_r16(h, p, Bsz, INT32_MAX))) {
         // (measured at C3: the sorted walk pays for its probe and scatter launches from about 8 192 instances: 0.26 against 0.31 ms
         // at 16 384, 0.25 against 0.19 ms at 4 096)
         const int r16_order = h->opt.order < 0 ? ((T >= 4 && Bsz >= 8192) ? 1 : 0) : h->opt.order;
@@ -649,7 +688,7 @@ int lqmpc_max_vn_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, 
     if (rc) return rc;
     p.A = dA; p.B = dB; p.MV = dMV; p.status = dstatus; p.iters = diters;
     // (n <= 10 and a large batch: the packed kernel's one lane per instance wins the K-state loop, 0.24 against 0.36 ms at C2 x 65 536)
-    if (use_spec(h, nx, nu, N) && use_r16(h, p, Bsz, N * nu <= 10 ? 32768 : INT32_MAX)) return launch_r16_with_hand_back(h, p);
+    if (h->use_jit || (use_spec(h, nx, nu, N) && use_r16(h, p, Bsz, N * nu <= 10 ? 32768 : INT32_MAX))) return launch_r16_with_hand_back(h, p);
     return launch(h, p);
 }
 
@@ -666,7 +705,7 @@ int lqmpc_sweep_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, i
     KParams p;
     int rc = prepare(h, c, p);
     if (rc) return rc;
-    if (use_spec(h, nx, nu, N) && use_r16(h, p, Bsz, INT32_MAX)) {
+    if (h->use_jit || (use_spec(h, nx, nu, N) && use_r16(h, p, Bsz, INT32_MAX))) {
         // one launch: condensing and W once per instance, K open-loop QPs, then the closed loop
         p.A = dA; p.B = dB; p.x0 = dx0; p.JT = dJT; p.MV = dMV; p.status = dstatus; p.iters = diters;
         if (true_per_instance) { p.At = A_true; p.Bt = B_true; }

@@ -1,10 +1,23 @@
 // lqmpc_common.h -- kernel parameter block and fp64 device helpers shared by the HIP kernels.
 // gfx950 (MI355X) only.
 #pragma once
+// LQMPC_JIT: compiled at run time by hiprtc (lqmpc_jit.hip) -- the HIP device API is built in there, and the device headers
+// (this one, lqmpc_wg_linalg.h, lqmpc_r16_setup.h, lqmpc_r16_body.h) use no standard-library header, so that the run-time
+// compile depends on nothing outside the library.
+#ifndef LQMPC_JIT
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace lqmpc {
+
+// ---- compile-time loops without <utility>: f(ic<I0>{}) ... f(ic<I1 - 1>{}) ----
+template <int I> struct ic { static constexpr int value = I; };
+template <int I0, int I1, class F>
+__device__ __forceinline__ void sfor(F &&f)
+{
+    if constexpr (I0 < I1) { f(ic<I0>{}); sfor<I0 + 1, I1>(f); }
+}
 
 enum Mode : int { MODE_SOLVE = 0, MODE_ROLLOUT = 1, MODE_MAXVN = 2, MODE_PROBE = 3, MODE_SWEEP = 4 /* max V_N, then the rollout */ };
 

@@ -409,11 +409,29 @@ __device__ static double value_fn(const Ctx &c)
     return cost;
 }
 
+// one instance: b = its index in the caller's arrays, col = its workspace column
+__device__ static void generic_instance(const KParams &p, long long b, long long col);
+
 __global__ void __launch_bounds__(64) lqmpc_generic_kernel(KParams p)
 {
     const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
     if (b >= p.Bsz) return;
-    Ctx c{p, gen_offsets(p.nx, p.nu, p.N), p.ws, b, p.ws_stride, p.nx, p.nu, p.N, p.n};
+    generic_instance(p, b, b);
+}
+
+// over a device-side list (p.perm, *p.count_dev entries: what a 16-lane-row kernel handed back): every thread owns one workspace
+// column and walks the list with the stride of the grid
+__global__ void __launch_bounds__(64) lqmpc_generic_list_kernel(KParams p)
+{
+    const long long col = (long long)blockIdx.x * 64 + threadIdx.x, cols = (long long)gridDim.x * 64;
+    const long long count = *p.count_dev;
+    for (long long s = col; s < count; s += cols) generic_instance(p, p.perm[s], col);
+}
+
+__device__ static void generic_instance(const KParams &p, long long b, long long col)
+{
+    // (the workspace macro indexes by b: shift the base so that column `col` is used)
+    Ctx c{p, gen_offsets(p.nx, p.nu, p.N), p.ws + (col - b), b, p.ws_stride, p.nx, p.nu, p.N, p.n};
     double *ws = c.ws; const long long stride = c.stride, Bsz = p.Bsz;
     const int nx = c.nx, nu = c.nu; const GenOff &o = c.o;
     const double *sh = p.sh, *Q = sh + p.so.Q, *R = sh + p.so.R;
@@ -464,6 +482,11 @@ __global__ void __launch_bounds__(64) lqmpc_generic_kernel(KParams p)
     }
     if (p.status) p.status[b] = status;
     if (p.iters) p.iters[b] = iters;
+}
+
+void launch_generic_list(const KParams &p, int cols, hipStream_t stream)
+{
+    hipLaunchKernelGGL(lqmpc_generic_list_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(64), 0, stream, p);
 }
 
 void launch_generic(const KParams &p, hipStream_t stream)

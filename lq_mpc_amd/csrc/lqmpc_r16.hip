@@ -21,6 +21,7 @@
 // An instance whose active set does not settle within the iteration cap is reported with status 3 internally; the
 // host re-runs exactly those instances on the packed kernel (interior point + active-set finishing) in a second
 // launch over a device-side list.
+#include <cstdio>
 #include "lqmpc_r16_body.h"
 
 namespace lqmpc {
@@ -31,7 +32,9 @@ namespace lqmpc {
 template <int NX, int NU, int N, int MODE, int LPI>
 struct R16Build {
     static constexpr int OCC = ((LPI == 16 && N * NU > 10) || LPI == 64) ? 2 : 1;
-    static constexpr int WAVES = (OCC == 2 || (N * NU <= 10 && LPI == 16)) ? 2 : 1;
+    // two waves per SIMD only where their LDS fits as well ((2,1,30): 33 KB per wavefront -> one wave, the whole register file)
+    static constexpr long long LDS_BYTES = (long long)(64 / LPI) * R16<NX, NU, N, LPI, (OCC == 2)>::INST * 8;
+    static constexpr int WAVES = ((OCC == 2 || (N * NU <= 10 && LPI == 16)) && LDS_BYTES * 8 <= 160 * 1024) ? 2 : 1;
 };
 
 template <int NX, int NU, int N, int MODE, int LPI>

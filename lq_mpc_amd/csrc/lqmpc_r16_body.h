@@ -3,8 +3,6 @@
 #pragma once
 #include "lqmpc_wg_linalg.h"
 #include "lqmpc_r16_setup.h"
-#include <cstdio>
-#include <utility>
 
 namespace lqmpc {
 
@@ -56,11 +54,7 @@ struct R16 {
     static constexpr int oP = 0, oW = PK, oR = 2 * PK, oX = oR + VEC, oY = oX + VEC, oL = oY + VEC;
     static constexpr int oC = oL + CS / 2;            // Q | R | A | B | P_T: the open-loop value function's constants (read from LDS
     static constexpr int CN = 3 * NX * NX + NU * NU + NX * NU;   // when built for two waves per SIMD)
-#ifdef LQMPC_R16_GJ_SETUP
-    static constexpr int SETUP = oW + 3 * n * NX + N * NX * NX;          // condensing tables alias the W region and what follows
-#else
     static constexpr int SETUP = n * NX;                                 // the hand-over of G aliases the P / W regions (lqmpc_r16_setup.h)
-#endif
     static constexpr int oG = 0;
     static constexpr int END = oC + CN + (CN & 1);
     static constexpr int oD = (END > SETUP) ? END : SETUP;        // a dummy slot BEHIND both: predicated LDS stores go there instead of toggling exec
@@ -169,54 +163,9 @@ __device__ __forceinline__ unsigned row_umax(unsigned x)
     return x;
 }
 
-// One wavefront's work: the four instances in slots slot0 .. slot0 + 3 (slots >= slot_end are surplus).
-// One pivot of the in-place Gauss-Jordan inversion (K is a template parameter so that every register index and
-// DPP control below is a constant: the optimizer does not fully unroll a loop of this size on its own).
-template <int K, int RB, int n, int LPI>
-__device__ __forceinline__ void gj_invert_step(double (&M)[RB][n], const int (&rw)[RB], bool &spd)
-{
-    constexpr int sk = K / LPI, lk = K % LPI;
-    isettle<LPI>(M[sk][K]);
-    const double d = ibcast<LPI>(M[sk][K], lk);
-    spd = spd && (d > 0.0);
-    const double inv = frcp1(d);
-    double g[RB];
-#pragma unroll
-    for (int s = 0; s < RB; ++s) {
-        const bool isk = (rw[s] == K);
-        g[s] = isk ? (inv - 1.0) : -M[s][K] * inv;
-        M[s][K] = isk ? 1.0 : 0.0;
-    }
-#pragma unroll
-    for (int j0 = 0; j0 < n; j0 += 4) {
-        if (j0 + 4 <= n && (K < j0 || K >= j0 + 4)) {                 // a whole group of four columns away from the pivot's
-#pragma unroll
-            for (int s = 0; s < RB; ++s)
-                if (s != sk) ifmac4<LPI>(&M[s][j0], &M[sk][j0], g[s], lk);   // the pivot row's own slot last: it rescales the row the others read
-            ifmac_self4<LPI>(&M[sk][j0], g[sk], lk);
-        } else {
-#pragma unroll
-            for (int j = j0; j < (j0 + 4 < n ? j0 + 4 : n); ++j) {
-#pragma unroll
-                for (int s = 0; s < RB; ++s)
-                    if (s != sk) ifmac<LPI>(M[s][j], M[sk][j], g[s], lk);
-                if (j == K) ifmac<LPI>(M[sk][j], M[sk][j], g[sk], lk);       // (column K was written just above: DPP wait states)
-                else ifmac_self<LPI>(M[sk][j], g[sk], lk);
-            }
-        }
-    }
-}
-template <int RB, int n, int LPI, int... K>
-__device__ __forceinline__ void gj_invert(double (&M)[RB][n], const int (&rw)[RB], bool &spd, std::integer_sequence<int, K...>)
-{
-    (gj_invert_step<K, RB, n, LPI>(M, rw, spd), ...);
-}
-
-// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, CNT - 1>)
-template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+// compile-time loop: f(ic<0>{}) ... f(ic<CNT - 1>{})
 template <int CNT, typename F>
-__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, CNT>{}); }
+__device__ __forceinline__ void static_for(F &&f) { sfor<0, CNT>(f); }
 
 // OCC = 2: built for two waves per SIMD (256 registers): the horizon loops of the condensing stay rolled and the stage weights
 // and the plant live in LDS instead of registers (they are the loop-invariant values the allocator would otherwise reload
@@ -233,9 +182,6 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     ldsd *L = (ldsd *)lds_raw + q * C::INST;
     ldsd *Pp = L + C::oP, *Wp = L + C::oW, *rL = L + C::oR, *xL = L + C::oX, *yL = L + C::oY;
     ldsi *list = (ldsi *)(L + C::oL);
-#ifdef LQMPC_R16_GJ_SETUP
-    constexpr int DUMMY = C::oD - C::oP, DUMMYW = C::oD - C::oW;     // the dummy slot as an index into P / W
-#endif
     const long long Bsz = p.Bsz;
     const long long b_raw = slot0 + q;
     const bool valid = b_raw < slot_end;
@@ -274,7 +220,6 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     long long prof_slowt = 0;
     long long prof_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-#ifndef LQMPC_R16_GJ_SETUP
     {
         // Set-up on the matrix core (lqmpc_r16_setup.h): Riccati recursion, W by rank-NU tile updates, G from the same sweep, P from
         // its Toeplitz form -- v_mfma_f64_4x4x4_4b_f64 products only.  MFMA block g = (lane >> 2) & 3 works for the instance of lanes
@@ -361,244 +306,6 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
         }
         RPROF(6);
     }
-#else
-    {
-        RPROF_START;
-        ldsd *MA = Wp, *PM = MA + n * NX, *QM = PM + n * NX, *AP = QM + n * NX;
-        static_assert(NX * NX <= LPI, "one lane per element of a power of A");
-        auto gA = [&](int a, int c) -> double { return p.rec ? p.rec[b * REC + a * NX + c] : p.A[(long long)(a * NX + c) * Bsz + b]; };
-        auto gB = [&](int a, int k) -> double { return p.rec ? p.rec[b * REC + NX * NX + a * NU + k] : p.B[(long long)(a * NU + k) * Bsz + b]; };
-        double ma[RB][NX], bcol[RB][NX];         // my rows' columns of A^a B, and of B itself
-        {   // the powers of A, one element per lane: A^(m+1)(ea, ek) = A(ea, :) . A^m(:, ek), through the table itself
-            const bool el = i < NX * NX;
-            const int ea = el ? i / NX : 0, ek = el ? i % NX : 0;
-            double Ar[NX];
-#pragma unroll
-            for (int c = 0; c < NX; ++c) Ar[c] = gA(ea, c);
-            // ... and, riding on the same stages, the recursion Lt_N = P_T, Lt_k = Q + A' Lt_{k+1} A of the condensing below (stage m
-            // makes A^(m+1) and Lt_(N-m); the two chains are independent, so the second costs one more barrier per stage, not N more)
-            constexpr int NN_ = NX * NX;
-            ldsd *LT_ = PM;
-            const double qe = el ? sh[p.so.Q + ea * NX + ek] : 0.0;
-            if (el) { AP[i] = gA(ea, ek); LT_[(N - 1) * NN_ + i] = sh[p.so.P + ea * NX + ek]; }
-#pragma unroll 1
-            for (int m = 1; m < N; ++m) {
-                const int k = N - m;
-                __syncthreads();
-                double t = 0.0, t1 = 0.0;
-#pragma unroll
-                for (int c = 0; c < NX; ++c) {
-                    t = __builtin_fma(Ar[c], AP[(m - 1) * NN_ + c * NX + ek], t);
-                    t1 = __builtin_fma(LT_[k * NN_ + ea * NX + c], AP[c * NX + ek], t1);      // (Lt_{k+1} A)(ea, ek)
-                }
-                if (el) { AP[m * NN_ + i] = t; Pp[i] = t1; }       // (the P region is free until the rows of P are written below)
-                __syncthreads();
-                double t2 = qe;                                      // Q + (A' (Lt_{k+1} A))(ea, ek)
-#pragma unroll
-                for (int c = 0; c < NX; ++c) t2 = __builtin_fma(AP[c * NX + ea], Pp[c * NX + ek], t2);
-                if (el) LT_[(k - 1) * NN_ + i] = t2;
-            }
-            __syncthreads();
-            // my rows' columns of M_a = A^a B
-#pragma unroll
-            for (int s = 0; s < RB; ++s) {
-                const int mm = vrow[s] ? N - 1 - rw[s] / NU : 0, uk = rw[s] % NU;
-                const int base = (mm > 0 ? mm - 1 : 0) * NX * NX;
-                double bk[NX];
-#pragma unroll
-                for (int a = 0; a < NX; ++a) { bk[a] = gB(a, uk); bcol[s][a] = bk[a]; }
-#pragma unroll
-                for (int a = 0; a < NX; ++a) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int c = 0; c < NX; ++c) t = __builtin_fma(AP[base + a * NX + c], bk[c], t);
-                    ma[s][a] = vrow[s] ? (mm > 0 ? t : bk[a]) : 0.0;
-                }
-            }
-        }
-        RPROF(0);
-        // Condensing through the Lyapunov-type recursion (round 2; it replaced the products T(i,j) = m_i'P_T m_j + ..., their sums along
-        // the stage diagonals and a horizon-long loop for the Fq rows).  With Lt_k = sum_{r >= k} (A')^(r-k) Q_r A^(r-k), i.e.
-        //   Lt_N = P_T,   Lt_k = Q + A' Lt_{k+1} A      (N - 1 stage updates of an NX x NX matrix, one element per lane),
-        // and y_i = Lt_{bi+1} b_ui for row i = (stage bi, input ui):
-        //   H(i, j) = y_i . m_(bi-bj),uj = y_i . MA[j + a_i NU]   (j <= i: ONE NX-term dot product per entry of the triangle),
-        //   Fq(i, :) = 2 y_i' A^(bi+1)                             (one NX x NX product per row),
-        // because Gamma'Qbar Gamma's block (bi, bj) is B' Lt_{bi+1} A^(bi-bj) B and Gamma'Qbar Phi's block row bi is B' Lt_{bi+1} A^(bi+1).
-        static_assert(2 * NU >= NX, "the table of the Lt_k takes the place of two row-image tables");
-        constexpr int NN = NX * NX;
-        ldsd *LT = PM;                                   // Lt_k at LT[(k-1) NN ..], k = 1..N
-        // (the recursion itself ran with the powers of A above)
-#pragma unroll
-        for (int s = 0; s < RB; ++s) {
-            if (vrow[s]) {
-#pragma unroll
-                for (int a = 0; a < NX; ++a) MA[rw[s] * NX + a] = ma[s][a];
-            }
-        }
-        __syncthreads();
-        RPROF(1);
-        double Facc[RB][NX];
-#pragma unroll
-        for (int s = 0; s < RB; ++s) {
-            const int bi = vrow[s] ? rw[s] / NU : 0, ui = rw[s] % NU;
-            double yv[NX], rrow[NU];
-#pragma unroll
-            for (int x = 0; x < NX; ++x) {
-                double t = 0.0;
-#pragma unroll
-                for (int l = 0; l < NX; ++l) t = __builtin_fma(LT[bi * NN + x * NX + l], bcol[s][l], t);
-                yv[x] = vrow[s] ? t : 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k < NU; ++k) rrow[k] = sh[p.so.R + ui * NU + k];
-            // my row of P = 2 (H + Rbar), columns j <= i
-            const ldsd *MAi = MA + (N - 1 - bi) * NU * NX;
-#pragma unroll
-            for (int j = 0; j < n; ++j) {
-                if (j >= LPI * (s + 1)) continue;                      // static: beyond the last row of this slot
-                double t = 0.0;
-#pragma unroll
-                for (int x = 0; x < NX; ++x) t = __builtin_fma(yv[x], MAi[j * NX + x], t);
-                const double radd = (j / NU == bi) ? rrow[j % NU] : 0.0;
-                Pp[(vrow[s] && j <= rw[s]) ? ad(rw[s], tri[s], j) : DUMMY] = 2.0 * (t + radd);
-                if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // straight-line code: keep the loads near their use
-            }
-            // my row of Fq
-#pragma unroll
-            for (int c = 0; c < NX; ++c) {
-                double t = 0.0;
-#pragma unroll
-                for (int x = 0; x < NX; ++x) t = __builtin_fma(yv[x], AP[bi * NN + x * NX + c], t);
-                Facc[s][c] = vrow[s] ? 2.0 * t : 0.0;
-            }
-        }
-        __syncthreads();
-        double Wr[RB][n];                       // my rows, both triangles
-#pragma unroll
-        for (int s = 0; s < RB; ++s)
-#pragma unroll
-            for (int j = 0; j < n; ++j) {
-                const int idx = PACKED ? ad(rw[s], tri[s], j) : ((j <= rw[s]) ? rw[s] * LDW + j : j * LDW + rw[s]);
-                const double t = Pp[vrow[s] ? idx : 0];
-                Wr[s][j] = vrow[s] ? t : 0.0;
-                if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
-            }
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < RB; ++s)
-#pragma unroll
-            for (int j = 0; j < n; ++j)
-                if (!PACKED) Pp[(vrow[s] && j > rw[s]) ? rw[s] * LDW + j : DUMMY] = Wr[s][j];   // the upper triangle: rows are stored in full
-        RPROF(2);
-        __builtin_amdgcn_sched_barrier(0);
-        RPROF(3);
-        // constant part of the linear term: qr = 2 gref + P centre (references / off-centre boxes only)
-        const bool has_lin = p.has_lin != 0;         // (decided on the host: here it cost 2 NU dependent loads of the shared block per wavefront)
-        double qr[RB];
-#pragma unroll
-        for (int s = 0; s < RB; ++s) qr[s] = 0.0;
-        if (has_lin) {
-            if (p.has_ref) {
-                //   d_r = -xref_r,  lam_r = Q_r d_r + A' lam_{r+1},  gref_r = B' lam_r - R uref_r   (columns r <-> x_{r+1}, u_r)
-                long long br = b;
-                asm volatile("" : "+v"(br));
-                double lam[NX], A2[NX][NX], B2[NX][NU];       // the model again: not kept live across the condensing above
-#pragma unroll
-                for (int a = 0; a < NX; ++a) {
-                    lam[a] = 0.0;
-#pragma unroll
-                    for (int c = 0; c < NX; ++c) A2[a][c] = p.rec ? p.rec[br * REC + a * NX + c] : p.A[(long long)(a * NX + c) * Bsz + br];
-#pragma unroll
-                    for (int k = 0; k < NU; ++k) B2[a][k] = p.rec ? p.rec[br * REC + NX * NX + a * NU + k] : p.B[(long long)(a * NU + k) * Bsz + br];
-                }
-#pragma unroll 1
-                for (int r = N - 1; r >= 0; --r) {
-                    const int oQ = (r < N - 1) ? p.so.Q : p.so.P;
-                    double l2[NX];
-#pragma unroll
-                    for (int a = 0; a < NX; ++a) {
-                        double t = 0.0;
-#pragma unroll
-                        for (int c = 0; c < NX; ++c) t = __builtin_fma(sh[oQ + a * NX + c], -sh[p.so.xref + c * N + r], t);
-#pragma unroll
-                        for (int c = 0; c < NX; ++c) t = __builtin_fma(A2[c][a], lam[c], t);
-                        l2[a] = t;
-                    }
-#pragma unroll
-                    for (int a = 0; a < NX; ++a) lam[a] = l2[a];
-#pragma unroll
-                    for (int s = 0; s < RB; ++s) {
-                        const int ui = rw[s] % NU;
-                        double t = 0.0;
-#pragma unroll
-                        for (int k = 0; k < NU; ++k) {
-                            double tk = 0.0;
-#pragma unroll
-                            for (int a = 0; a < NX; ++a) tk = __builtin_fma(B2[a][k], lam[a], tk);
-#pragma unroll
-                            for (int j = 0; j < NU; ++j) tk = __builtin_fma(-sh[p.so.R + k * NU + j], sh[p.so.uref + j * N + r], tk);
-                            t = (ui == k) ? tk : t;
-                        }
-                        qr[s] = (vrow[s] && rw[s] / NU == r) ? 2.0 * t : qr[s];
-                    }
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < RB; ++s) {
-                double t = qr[s];
-#pragma unroll
-                for (int j = 0; j < n; ++j) t = __builtin_fma(Wr[s][j], 0.5 * (sh[p.so.ub + j % NU] + sh[p.so.lb + j % NU]), t);
-                qr[s] = vrow[s] ? t : 0.0;
-            }
-        }
-        __syncthreads();                       // the tables in the W region are dead from here
-        __builtin_amdgcn_sched_barrier(0);
-        // W = P^-1 by Gauss-Jordan elimination in place: per pivot k the pivot row reaches every lane through
-        // the DPP operand of the update, row_i += g_i * row_k with g_i = -a_ik / a_kk (g_k = 1/a_kk - 1 scales
-        // the pivot row itself); column k is set to e_k first so that it ends up holding column k of the inverse.
-        bool spd = true;
-        RPROF(4);
-        gj_invert<RB, n, LPI>(Wr, rw, spd, std::make_integer_sequence<int, n>{});
-        RPROF(5);
-        // [G | v_r] = -W [Fq | qr]: row i of W is in my registers, row j of [Fq | qr] comes by row broadcast
-#pragma unroll
-        for (int s = 0; s < RB; ++s) {
-            vr[s] = 0.0;
-#pragma unroll
-            for (int a = 0; a < NX; ++a) G[s][a] = 0.0;
-        }
-        static_for<n>([&](auto jc) {                        // (a plain loop with the DPP switch inside is not fully unrolled)
-            constexpr int j = decltype(jc)::value, sj = j / LPI, lj = j % LPI;
-#pragma unroll
-            for (int s = 0; s < RB; ++s) {
-                const double nw = -Wr[s][j];
-                if constexpr (NX == 4) ifmac4<LPI>(&G[s][0], &Facc[sj][0], nw, lj);
-                else {
-#pragma unroll
-                    for (int a = 0; a < NX; ++a) ifmac<LPI>(G[s][a], Facc[sj][a], nw, lj);
-                }
-                if (has_lin) ifmac<LPI>(vr[s], qr[sj], nw, lj);
-            }
-        });
-#pragma unroll
-        for (int s = 0; s < RB; ++s) {
-#pragma unroll
-            for (int j = 0; j < n; ++j)
-                Wp[(vrow[s] && (!PACKED || j <= rw[s])) ? ad(rw[s], tri[s], j) : DUMMYW] = Wr[s][j];
-            if (!vrow[s]) {
-                vr[s] = 0.0;
-#pragma unroll
-                for (int a = 0; a < NX; ++a) G[s][a] = 0.0;
-            }
-        }
-        if (!spd) {
-#pragma unroll
-            for (int s = 0; s < RB; ++s) vr[s] = __builtin_nan("");
-        }
-        __syncthreads();
-        RPROF(6);
-    }
-#endif
     RPROF_START;
     RPROF_ADD(13, clock64() - prof_t0);
 
@@ -650,9 +357,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     const bool writer = valid && i == 0;
     mask_t pL = 0, pU = 0;                  // active set of the previous step (row-uniform bit masks)
     int iters = 0, status = 0;
-#ifndef LQMPC_R16_GJ_SETUP
     bool P_ready = false;                   // P is built the first time an iteration of this wavefront takes the primal side (r16_build_P)
-#endif
     // ---- one box QP at state x: v <- the optimum (my rows); updates the warm-start face, iters, status ----
     auto qp = [&](const double (&x)[NX], double (&v)[RB]) {
         double vu[RB];
@@ -699,7 +404,6 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                              max(__builtin_amdgcn_readlane(c, 32), __builtin_amdgcn_readlane(c, 48)));
                 else cw = __builtin_amdgcn_readfirstlane(c);
                 const bool any_primal = __ballot(busy && !dual) != 0ull;
-#ifndef LQMPC_R16_GJ_SETUP
                 if (any_primal && !P_ready) {                    // wave-uniform
                     long long bg = bq;
                     ldsd *Lg = L;
@@ -712,7 +416,6 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                     r16_build_P<NX, NU, N, LPI, PACKED>(setup_args(p), bg, Lg, C::oP, C::oD);
                     P_ready = true;
                 }
-#endif
                 if constexpr (LPI == 16) {
                     if (!any_primal) {
                         // ---- every busy instance of the wavefront is on the dual side: W_AA lam = r_A, v_F = v_unc,F - W_FA lam ----

@@ -3,6 +3,7 @@
 // A batch that does not fill the chip past one wave per SIMD (<= 4096 instances) gains nothing from the second
 // wave and runs 10-30 % faster on this build (one-shot 1024 instances of C3: 56 us vs 67 us); the host picks by batch
 // size (launch_r16).  Same algorithm and iteration; the two builds differ in unrolling and in where the constants live.
+#include <cstdio>
 #include "lqmpc_r16_body.h"
 
 namespace lqmpc {

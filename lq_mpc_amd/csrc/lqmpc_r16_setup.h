@@ -26,18 +26,13 @@
 // wavefront first needs it (r16_build_P: the primal side of an iteration).
 #pragma once
 #include "lqmpc_wg_linalg.h"
-#include <utility>
 
 namespace lqmpc {
 
+constexpr int SETUP_MAX_NX = 4, SETUP_MAX_NU = 2;   // what this set-up serves (the run-time compile asks: lqmpc_jit.hip)
+
 // (a)' b + c on register matrices (four independent blocks per wavefront)
 __device__ __forceinline__ double mm4(double a, double b, double c = 0.0) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
-
-template <int I0, int I1, class F>
-__device__ __forceinline__ void sfor(F &&f)
-{
-    if constexpr (I0 < I1) { f(std::integral_constant<int, I0>{}); sfor<I0 + 1, I1>(f); }
-}
 
 template <int NX, int NU, int N, int LPI>
 struct SetupT {

@@ -12,8 +12,6 @@
 //   row broadcasts) and inverts it in the same pass, while waves 1..3 update the rest; barrier.
 // After it: strict lower blocks hold L, diagonal blocks hold L_kk (lower triangle), Linv holds L_kk^-1.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <type_traits>
 #include "lqmpc_common.h"
 
 namespace lqmpc {
@@ -295,10 +293,7 @@ __device__ __forceinline__ double frsqrt1(double x)
 // the unroller prices the lane switch of every rowb helper at all 16 cases and then refuses to unroll fully -- which would leave the
 // row registers indexed at run time (s_set_gpr_idx) and every broadcast behind a jump table.
 template <int I0, int I1, class F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (I0 < I1) { f(std::integral_constant<int, I0>{}); static_for<I0 + 1, I1>(f); }
-}
+__device__ __forceinline__ void static_for(F &&f) { sfor<I0, I1>(f); }
 
 // One wave: factor the diagonal block D (in place: lower triangle <- L, upper <- 0) and write its inverse
 // (lower triangular) to Dinv.  Returns false on a non-positive pivot.

@@ -30,7 +30,7 @@ def test_version_and_defaults():
     L.lqmpc_default_options(ctypes.byref(o))
     assert o.eps == 1e-12 and o.max_iter == 50 and o.polish == 1 and o.kernel == _lib.KERNEL_AUTO and o.presolve == -1 and o.order == -1 and o.warm_start == -1
     assert o.layout == -1 and o.r16_maxit == 12 and o.r16_build == -1 and o.nwide == -1
-    assert ctypes.sizeof(_lib.Options) == 72 and o.struct_size == 72 and o.reserved == 0      # the struct carries its own size (ABI 0.2.0)
+    assert ctypes.sizeof(_lib.Options) == 80 and o.struct_size == 80 and o.reserved == 0 and o.jit == -1     # the struct carries its own size (ABI 0.2.0)
 
 
 def test_no_device_is_an_error_not_a_fallback():

@@ -336,6 +336,13 @@ def test_difficulty_ordering_is_transparent(solver, golden_dir):
 
 # ---------------- stress: random shapes of cost, box, conditioning on the specialised shapes ----------------
 WG_SHAPES = [(8, 4, 30), (6, 3, 15), (16, 2, 17), (3, 2, 64), (5, 1, 33)]     # n = 120, 45, 34, 128, 33
+PREBUILT = [(4, 2, 10), (2, 1, 10), (2, 1, 5), (2, 1, 7), (2, 1, 20), (2, 1, 30), (4, 2, 20)]
+JIT_MAX_NX, JIT_MAX_NU = 4, 2              # lqmpc_r16_setup.h: SETUP_MAX_NX / SETUP_MAX_NU
+
+
+def jit_domain(nx, nu, N):
+    """Shapes the run-time compiled 16-lane-row kernel serves (lqmpc_jit.hip: jit_r16_shape)."""
+    return nx <= JIT_MAX_NX and nu <= JIT_MAX_NU and N * nu <= 48
 
 
 @pytest.mark.parametrize("nx,nu,N", [(4, 2, 10), (2, 1, 10), (2, 1, 5), (2, 1, 7), (2, 1, 20), (2, 1, 30), (3, 2, 6), (1, 1, 1), (5, 3, 4), (4, 2, 20)] + WG_SHAPES)
@@ -345,8 +352,8 @@ def test_random_problems(solver, nx, nu, N, warm):
     specialised shapes (warm start on / off), on shapes only the generic kernel covers, and on the
     one-instance-per-workgroup shapes (32 < n <= 128, including stages that straddle the 16-row blocks)."""
     rng = np.random.default_rng(100 * nx + N + warm)
-    wg = (nx, nu, N) in WG_SHAPES
-    Bsz, T = (96, 6) if wg else (768, 12)
+    wg = (nx, nu, N) in WG_SHAPES and not jit_domain(nx, nu, N)
+    Bsz, T = (96, 6) if (nx, nu, N) in WG_SHAPES else (768, 12)
     A = rng.standard_normal((nx, nx, Bsz))
     rho_hi = 1.3 if N <= 20 else 200.0 ** (1.0 / N)           # keeps rho^N (the conditioning of the condensed Hessian) bounded
     A *= rng.uniform(0.3, rho_hi, Bsz) / np.abs(np.linalg.eigvals(A.transpose(2, 0, 1))).max(axis=1)   # spectral radius in [0.3, rho_hi]
@@ -374,8 +381,10 @@ def test_random_problems(solver, nx, nu, N, warm):
             g1 = solver.solve_batch(N, A, B, Q, R, P, lb, ub, x0, xr, ur)
             g2 = solver.rollout_batch(T, N, A, B, Q, R, P, lb, ub, x0, At, Bt, xr, ur, want_traj=True)
             k = solver.last_kernel()                                  # packed or 16-lane-row specialisation (small batches, warm start on)
-            assert ("spec" in k or "r16" in k or "r64" in k) == ((nx, nu, N) in [(4, 2, 10), (2, 1, 10), (2, 1, 5), (2, 1, 7), (2, 1, 20), (2, 1, 30), (4, 2, 20)])
-            assert ("wg" in solver.last_kernel()) == wg
+            jit = warm == 1 and (nx, nu, N) not in PREBUILT and jit_domain(nx, nu, N)      # compiled at run time (presolve + warm start: its algorithm)
+            assert ("spec" in k or "r16" in k or "r64" in k) == ((nx, nu, N) in PREBUILT or jit)
+            assert ("jit" in k) == jit
+            assert ("wg" in k) == (wg or ((nx, nu, N) in WG_SHAPES and not jit))
         finally:
             solver.set_options(warm_start=-1, presolve=-1, r16_build=-1)
         assert np.all(g1["status"] == 0)
@@ -587,3 +596,54 @@ def test_ordered_rollout_growing_batch_on_one_handle(golden_dir):
         assert rel(g["J_T"][:m], ref["J_T"]) < TIGHT
     finally:
         s.close(); s2.close()
+
+
+@pytest.mark.parametrize("nx,nu,N", [(3, 2, 6), (1, 1, 1), (2, 1, 12), (4, 2, 12), (3, 1, 10), (4, 2, 16), (4, 2, 24), (2, 1, 40)])
+def test_run_time_compiled_shapes(solver, nx, nu, N):
+    """Shapes without a prebuilt instantiation get the 16-lane-row kernel compiled at run time (lqmpc_jit.hip; utils_class.py:23, 62:
+    the reference takes any N): every entry point, the ordered walk (probe compiled too), the hand-back to the generic kernel over
+    the device-side list (iteration cap forced to 1), and options.jit = 0 (generic kernel) must all agree with the oracle."""
+    rng = np.random.default_rng(1000 * nx + 10 * N + nu)
+    Bsz, T, m = 8192 + 5, 8, 320
+    A = rng.standard_normal((nx, nx, Bsz))
+    A *= rng.uniform(0.4, 1.15, Bsz) / np.abs(np.linalg.eigvals(A.transpose(2, 0, 1))).max(axis=1)
+    B = rng.standard_normal((nx, nu, Bsz)) * rng.uniform(0.2, 1.5, (1, 1, Bsz))
+    M = rng.standard_normal((nx, nx)); Q = M @ M.T / nx + np.eye(nx)
+    M = rng.standard_normal((nu, nu)); R = 0.3 * (M @ M.T / nu + np.eye(nu))
+    P = 2.5 * Q
+    lb, ub = -rng.uniform(0.05, 0.3, nu), rng.uniform(0.05, 0.3, nu)
+    x0 = rng.standard_normal((nx, Bsz)) * rng.choice([1e-2, 0.3, 1.0, 3.0], Bsz)
+    A, B = np.ascontiguousarray(A), np.ascontiguousarray(B)
+    At = np.ascontiguousarray(0.95 * A); Bt = B
+    x0s = np.ascontiguousarray(rng.standard_normal((nx, 5)))
+    umax = float(np.max(np.maximum(-lb, ub)))
+    sub = lambda a: np.ascontiguousarray(a[..., :m])
+    r1 = orc.solve_batch(N, sub(A), sub(B), Q, R, P, lb, ub, sub(x0))
+    r2 = orc.rollout_batch(T, N, sub(A), sub(B), Q, R, P, lb, ub, sub(x0), sub(At), sub(Bt), want_traj=True)
+    r3 = orc.max_vn_batch(N, sub(A), sub(B), Q, R, P, lb, ub, x0s)
+    ok = np.isfinite(r2["J_T"]) & (np.abs(r2["X"]).max(axis=(0, 1)) < 1e6)
+    assert ok.mean() > 0.5
+
+    def check(g1, g2, g3, g4):
+        assert np.all(g1["status"][:m] == 0) and np.all(g2["status"][:m][ok] == 0)
+        assert rel(g1["V_N"][:m], r1["V_N"]) < 1e-7 and u_err(g1["u_0"][:, :m], r1["u_0"], umax) < RTOL
+        assert rel(g2["J_T"][:m][ok], r2["J_T"][ok]) < 1e-6
+        assert rel(g3["M_V"][:m], r3) < 1e-7
+        assert rel(g4["M_V"][:m], r3) < 1e-7 and rel(g4["J_T"][:m][ok], r2["J_T"][ok]) < 1e-6
+    a = (N, A, B, Q, R, P, lb, ub)
+    try:
+        for cap in (12, 1):                       # 1: every constrained QP is handed back -> lqmpc_generic_list_kernel
+            solver.set_options(r16_maxit=cap)
+            g1 = solver.solve_batch(*a, x0); k1 = solver.last_kernel()
+            g2 = solver.rollout_batch(T, *a, x0, At, Bt); k2 = solver.last_kernel()           # 8197 instances, T = 8: the ordered walk
+            g3 = solver.max_vn_batch(*a, x0s); k3 = solver.last_kernel()
+            g4 = solver.sweep_batch(T, *a, x0, x0s, At, Bt); k4 = solver.last_kernel()
+            for k in (k1, k2, k3, k4):
+                assert "jit" in k and (f"<{nx},{nu},{N}>" in k) and ("r16" in k) == (N * nu <= 32), k
+            check(g1, g2, g3, g4)
+        solver.set_options(r16_maxit=12, jit=0)
+        h1 = solver.solve_batch(N, sub(A), sub(B), Q, R, P, lb, ub, sub(x0))
+        assert "jit" not in solver.last_kernel()
+        assert rel(h1["V_N"], g1["V_N"][:m]) < 1e-7
+    finally:
+        solver.set_options(r16_maxit=12, jit=-1)
