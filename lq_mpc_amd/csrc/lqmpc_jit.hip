@@ -45,7 +45,8 @@ static int r16_inst(int nx, int nu, int N, int lpi, bool packed)
 {
     const int n = N * nu, rb = (n + lpi - 1) / lpi, cs = lpi == 16 ? 16 : 24, ldw = n + 1;
     const int pk = packed ? n * (n + 1) / 2 : n * ldw, vec = lpi * rb;
-    const int oR = 2 * pk, oL = oR + 3 * vec, oC = oL + cs / 2, cn = 3 * nx * nx + nu * nu + nx * nu;
+    const int cn0 = 3 * nx * nx + nu * nu + nx * nu, cn1 = (nx > nu ? nx : nu) * (2 * nx + 2 * nu), cn = cn0 > cn1 ? cn0 : cn1;
+    const int oR = 2 * pk, oL = oR + 3 * vec, oC = oL + cs / 2;
     const int setup = n * nx, end = oC + cn + (cn & 1), oD = end > setup ? end : setup;
     return oD + 2;
 }

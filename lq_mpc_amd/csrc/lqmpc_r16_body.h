@@ -53,7 +53,9 @@ struct R16 {
     // LDS per instance, in doubles: P | W | r | x | y | list (CS ints)
     static constexpr int oP = 0, oW = PK, oR = 2 * PK, oX = oR + VEC, oY = oX + VEC, oL = oY + VEC;
     static constexpr int oC = oL + CS / 2;            // Q | R | A | B | P_T: the open-loop value function's constants (read from LDS
-    static constexpr int CN = 3 * NX * NX + NU * NU + NX * NU;   // when built for two waves per SIMD)
+    static constexpr int CN0 = 3 * NX * NX + NU * NU + NX * NU;  // when built for two waves per SIMD)
+    static constexpr int CN1 = (NX > NU ? NX : NU) * (2 * NX + 2 * NU);   // ... or the closed loop's per-lane rows of [A_true B_true | Q | R]
+    static constexpr int CN = CN0 > CN1 ? CN0 : CN1;
     static constexpr int SETUP = n * NX;                                 // the hand-over of G aliases the P / W regions (lqmpc_r16_setup.h)
     static constexpr int oG = 0;
     static constexpr int END = oC + CN + (CN & 1);

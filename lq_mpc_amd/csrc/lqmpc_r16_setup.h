@@ -21,6 +21,10 @@
 //     W = (2H)^-1 = 1/2 T D^-1 T' = sum_M T(:, M) (D_M^-1 / 2) T(:, M)'       (one update per column tile M of 4 / NU stages, on 4x4 tiles),
 //     G rows of stage k = -K_k Acl_{k-1} .. Acl_0 = -rho_k(-1)                    (what the rows rho_k have become after stage 0),
 // and the rows rho_k advance inside the same backward sweep (rho_k(j-1) = rho_k(j) Acl_j), so nothing is stored per stage.
+// Sizes: state matrices of up to 8 x 8 are 2 x 2 tiles (TX = 2: every product of the recursion becomes TX^2..TX^3 tile products);
+// stage blocks of 1, 2 or 4 inputs tile the rows exactly, 3 inputs are padded to 4 with a dummy input (zero column of B, unit
+// weight: decoupled, its rows are never stored).  The inverse of Re for 4 inputs goes by 2 x 2 blocks (Schur complement), again
+// with products and element-wise reciprocals only.
 // P keeps its Lyapunov / Toeplitz form (round 2): block (bi, bj) = B' Lt_{bi+1} A^(bi-bj) B, Lt_N = P_T, Lt_k = Q + A'Lt_{k+1}A,
 // assembled tile by tile along the block diagonals so that the powers A^d B stream through one register -- and only when a
 // wavefront first needs it (r16_build_P: the primal side of an iteration).
@@ -29,48 +33,68 @@
 
 namespace lqmpc {
 
-constexpr int SETUP_MAX_NX = 4, SETUP_MAX_NU = 2;   // what this set-up serves (the run-time compile asks: lqmpc_jit.hip)
+constexpr int SETUP_MAX_NX = 8, SETUP_MAX_NU = 4;   // what this set-up serves (the run-time compile asks: lqmpc_jit.hip)
 
 // (a)' b + c on register matrices (four independent blocks per wavefront)
 __device__ __forceinline__ double mm4(double a, double b, double c = 0.0) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 
 template <int NX, int NU, int N, int LPI>
 struct SetupT {
-    static_assert(NX <= 4, "state matrices are one 4x4 tile");
-    static_assert(NU == 1 || NU == 2, "stage blocks of 1 or 2 rows (the small inverse of Re is written out for these)");
-    static constexpr int n = N * NU;
-    static constexpr int NT = (n + 3) / 4;                    // 4-row tiles of the n x n matrices
-    static constexpr int SPT = 4 / NU;                        // stages per tile
+    static_assert(NX >= 1 && NX <= SETUP_MAX_NX, "state matrices are at most 2 x 2 tiles of 4 x 4");
+    static_assert(NU >= 1 && NU <= SETUP_MAX_NU, "stage blocks of 1..4 rows");
+    static constexpr int TX = (NX + 3) / 4;                   // tiles per side of a state matrix
+    static constexpr int NUP = (NU == 3) ? 4 : NU;            // rows of a stage block in the tiled (padded) row space
+    static constexpr int n = N * NU, npad = N * NUP;
+    static constexpr int NT = (npad + 3) / 4;                 // 4-row tiles of the npad x npad matrices
+    static constexpr int SPT = 4 / NUP;                       // stages per tile
     static constexpr int NTM = (LPI == 16) ? NT : (NT + 3) / 4;   // tile registers: LPI = 64 deals tile I to block I % 4, register I / 4
-    static constexpr int tile_of_stage(int j) { return (j * NU) / 4; }
-    static constexpr int off_of_stage(int j) { return (j * NU) % 4; }
+    static constexpr int tile_of_stage(int j) { return (j * NUP) / 4; }
+    static constexpr int off_of_stage(int j) { return (j * NUP) % 4; }
     // has tile I rows of a stage beyond j (i.e. is its rho non-zero when stage j is processed)?
     static constexpr bool live(int I, int j) { return ((I + 1) * SPT < N ? (I + 1) * SPT : N) - 1 > j; }
-    static constexpr int GS = n * NX;                          // doubles of scratch for the hand-over of G
+    // row of the problem for a row of the tiled space (-1: a dummy input's row, or beyond the horizon)
+    __device__ static __forceinline__ int row_of(int rp) { return (rp < npad && rp % NUP < NU) ? (rp / NUP) * NU + rp % NUP : -1; }
 };
 
-// Inverse of the leading NU x NU block of the register matrix Re (symmetric positive definite), zero elsewhere.  Not positive
-// definite: NaN (it spreads through every later product into G, and the solver hands the instance back).
-template <int NU>
+// Inverse of the 2 x 2 block at rows / columns o, o+1 of the register matrix M (symmetric positive definite there), zero elsewhere:
+// adj(M) = J M J' with J = [0 1; -1 0];  M adj(M) = det I;  det into all four lanes of the block by a product with ones.
+// Not positive definite: NaN (it spreads through every later product into G, and the solver hands the instance back).
+__device__ __forceinline__ double inv2(double M, int r, int c, int o)
+{
+    const bool in = r >= o && r < o + 2 && c >= o && c < o + 2;
+    const double Jt = (r == o && c == o + 1) ? -1.0 : ((r == o + 1 && c == o) ? 1.0 : 0.0);
+    const double ones = in ? 1.0 : 0.0;
+    const double blk = in ? M : 0.0;
+    const double adj = mm4(mm4(blk, Jt), Jt);
+    const double det = mm4(ones, mm4(blk, adj));
+    const double e00ok = (r == o && c == o && !(M > 0.0)) ? __builtin_nan("") : 1.0;
+    const double idet = (in && !(det > 0.0)) ? __builtin_nan("") : frcp(in ? det : 1.0);
+    return in ? adj * idet * e00ok : 0.0;
+}
+
+// Inverse of the leading NUP x NUP block of the register matrix Re (symmetric positive definite), zero elsewhere.
+template <int NUP>
 __device__ __forceinline__ double small_inverse(double Re, int r, int c)
 {
-    if constexpr (NU == 1) {
+    if constexpr (NUP == 1) {
         const double inv = (Re > 0.0) ? frcp(Re) : __builtin_nan("");
         return (r == 0 && c == 0) ? inv : 0.0;
+    } else if constexpr (NUP == 2) {
+        return inv2(Re, r, c, 0);
     } else {
-        // adj(Re) = J Re J' with J = [0 1; -1 0];  Re adj(Re) = det I;  det into all four lanes of the 2 x 2 block by a product with ones
-        const double Jt = (r == 0 && c == 1) ? -1.0 : ((r == 1 && c == 0) ? 1.0 : 0.0);
-        const double ones = (r < 2 && c < 2) ? 1.0 : 0.0;
-        const double adj = mm4(mm4(Re, Jt), Jt);
-        const double det = mm4(ones, mm4(Re, adj));
-        const bool in = r < 2 && c < 2;
-        const double e00ok = (r == 0 && c == 0 && !(Re > 0.0)) ? __builtin_nan("") : 1.0;
-        const double idet = (in && !(det > 0.0)) ? __builtin_nan("") : frcp(in ? det : 1.0);
-        return in ? adj * idet * e00ok : 0.0;
+        // [E F; F' H]^-1 by 2 x 2 blocks, S = H - F'E^-1 F:  [E^-1 + X S X', -X; -X', S^-1] with X = E^-1 F S^-1
+        const double Fb = (r < 2 && c >= 2) ? Re : 0.0;
+        const double Ei = inv2(Re, r, c, 0);
+        const double EiF = mm4(Ei, Fb);                                // E^-1 F      (rows 0-1, columns 2-3)
+        const double Sc = mm4(-Fb, EiF, (r >= 2 && c >= 2) ? Re : 0.0); // H - F'E^-1 F
+        const double Si = inv2(Sc, r, c, 2);
+        const double FtEi = mm4(Fb, Ei);                               // F'E^-1      (rows 2-3, columns 0-1)
+        const double X = mm4(FtEi, Si);                                // E^-1 F S^-1
+        const double Xt = mm4(Si, FtEi);                               // S^-1 F'E^-1
+        return mm4(Xt, FtEi, Ei) - X - Xt + Si;
     }
 }
 
-// Zero-padded loads of one instance's model (instance-minor arrays or the probe's instance-major records) and of the shared weights
 // what the set-up reads of the kernel parameters, by value (a reference to KParams passed to the non-inlined r16_build_P would
 // make the whole block address-taken: every later p.xxx becomes a scratch load instead of a scalar load of the kernel argument)
 struct SetupArgs {
@@ -80,6 +104,7 @@ struct SetupArgs {
 };
 __device__ __forceinline__ SetupArgs setup_args(const KParams &p) { return SetupArgs{p.rec, p.A, p.B, p.sh, p.Bsz, p.so.Q, p.so.P, p.so.R}; }
 
+// Zero-padded loads of one instance's model (instance-minor arrays or the probe's instance-major records) and of the shared weights
 template <int NX, int NU>
 struct ModelLd {
     const SetupArgs &p;
@@ -101,20 +126,20 @@ struct ModelLd {
     }
     __device__ __forceinline__ double S(int o, int a, int k, int dim) const
     {
-        const bool v = a < dim && k < dim;
+        const bool v = a >= 0 && k >= 0 && a < dim && k < dim;
         const double x = p.sh[o + (v ? a * dim + k : 0)];
         return v ? x : 0.0;
     }
 };
 
-// one 4x4 tile of a symmetric n x n matrix to LDS: lane (r, c) holds entry (4I + r, 4J + c); lower triangle only (packed), or both
-// triangles of full rows; predicated stores go to the dummy slot
-template <int n, bool PACKED>
+// one 4x4 tile of a symmetric matrix to LDS: lane (r, c) holds entry (4I + r, 4J + c) of the tiled row space; lower triangle only
+// (packed), or both triangles of full rows; predicated stores (upper triangle, dummy rows) go to the dummy slot
+template <class T, bool PACKED>
 __device__ __forceinline__ void store_tile(wg::ldsd *M, int dummy, int I, int J, double val, bool on, int r, int c)
 {
-    constexpr int LDW = n + 1;
-    const int row = 4 * I + r, col = 4 * J + c;
-    const bool low = on && row < n && col <= row;
+    constexpr int LDW = T::n + 1;
+    const int row = T::row_of(4 * I + r), col = T::row_of(4 * J + c);
+    const bool low = on && row >= 0 && col >= 0 && col <= row;
     if constexpr (PACKED) M[low ? row * (row + 1) / 2 + col : dummy] = val;
     else {
         M[low ? row * LDW + col : dummy] = val;
@@ -131,39 +156,73 @@ template <int NX, int NU, int N, int LPI, bool PACKED>
 __device__ __attribute__((noinline)) void r16_build_P(const SetupArgs p, long long bg, wg::ldsd *Lg, int oP, int oD)
 {
     using T = SetupT<NX, NU, N, LPI>;
-    constexpr int n = T::n, NT = T::NT, SPT = T::SPT, NTM = T::NTM;
+    constexpr int NT = T::NT, SPT = T::SPT, NTM = T::NTM, TX = T::TX, NUP = T::NUP;
     const int lane = threadIdx.x, r = lane >> 4, c = lane & 3, g = (lane >> 2) & 3;
-    const double *sh = p.sh;
     wg::ldsd *Pp = Lg + oP;
     const int dP = oD - oP;
     const ModelLd<NX, NU> ld{p, bg};
-    const double A = ld.A(r, c), At = ld.A(c, r), Q = ld.S(p.oQ, r, c, NX), PT = ld.S(p.oP, r, c, NX);
-    double Bpl[SPT];                                                  // B in column block q of a tile
+    double A[TX][TX], At[TX][TX], Q[TX][TX], Lt[TX][TX];
+    double Bpl[SPT][TX];                                              // B in column block q of a tile
 #pragma unroll
-    for (int qq = 0; qq < SPT; ++qq) Bpl[qq] = ld.B(r, c - qq * NU);
-    double ap[NTM][SPT];                                              // a-operands of my tiles' stages
+    for (int a = 0; a < TX; ++a) {
+#pragma unroll
+        for (int b = 0; b < TX; ++b) {
+            A[a][b] = ld.A(4 * a + r, 4 * b + c); At[a][b] = ld.A(4 * b + c, 4 * a + r);
+            Q[a][b] = ld.S(p.oQ, 4 * a + r, 4 * b + c, NX); Lt[a][b] = ld.S(p.oP, 4 * a + r, 4 * b + c, NX);
+        }
+#pragma unroll
+        for (int qq = 0; qq < SPT; ++qq) Bpl[qq][a] = ld.B(4 * a + r, c - qq * NUP);
+    }
+    double ap[NTM][SPT][TX];                                          // a-operands of my tiles' stages
 #pragma unroll
     for (int m = 0; m < NTM; ++m)
 #pragma unroll
-        for (int pp = 0; pp < SPT; ++pp) ap[m][pp] = 0.0;
-    double Lt = PT;
+        for (int pp = 0; pp < SPT; ++pp)
+#pragma unroll
+            for (int a = 0; a < TX; ++a) ap[m][pp][a] = 0.0;
     sfor<0, N>([&](auto kc) {
         constexpr int k = N - 1 - decltype(kc)::value;
         constexpr int I = k / SPT, pp = k % SPT;
-        const double v = mm4(Lt, Bpl[pp]);
-        if constexpr (LPI == 16) ap[I][pp] = v;
-        else ap[I / 4][pp] = (g == I % 4) ? v : ap[I / 4][pp];
-        if constexpr (k > 0) Lt = mm4(A, mm4(Lt, A), Q);
+#pragma unroll
+        for (int a = 0; a < TX; ++a) {
+            double v = 0.0;
+#pragma unroll
+            for (int k2 = 0; k2 < TX; ++k2) v = mm4(Lt[k2][a], Bpl[pp][k2], v);
+            if constexpr (LPI == 16) ap[I][pp][a] = v;
+            else ap[I / 4][pp][a] = (g == I % 4) ? v : ap[I / 4][pp][a];
+        }
+        if constexpr (k > 0) {
+            double LA[TX][TX];
+#pragma unroll
+            for (int a = 0; a < TX; ++a)
+#pragma unroll
+                for (int b = 0; b < TX; ++b) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int k2 = 0; k2 < TX; ++k2) v = mm4(Lt[k2][a], A[k2][b], v);
+                    LA[a][b] = v;
+                }
+#pragma unroll
+            for (int a = 0; a < TX; ++a)
+#pragma unroll
+                for (int b = 0; b < TX; ++b) {
+                    double v = Q[a][b];
+#pragma unroll
+                    for (int k2 = 0; k2 < TX; ++k2) v = mm4(A[k2][a], LA[k2][b], v);
+                    Lt[a][b] = v;
+                }
+        }
     });
     double Rd = 0.0;                                                  // R on the diagonal blocks of a diagonal tile
 #pragma unroll
     for (int qq = 0; qq < SPT; ++qq) {
-        const int rr = r - qq * NU, cc = c - qq * NU;
-        const bool v = rr >= 0 && rr < NU && cc >= 0 && cc < NU;
-        const double x = sh[p.oR + (v ? rr * NU + cc : 0)];
-        Rd = v ? x : Rd;
+        const int rr = r - qq * NUP, cc = c - qq * NUP;
+        const double x = ld.S(p.oR, rr, cc, NU);
+        Rd = (rr >= 0 && rr < NU && cc >= 0 && cc < NU) ? x : Rd;
     }
-    double X = Bpl[0];                                                // X_d = [A^d B | A^(d-1) B | ..] (columns of negative powers: zero)
+    double X[TX];                                                     // X_d = [A^d B | A^(d-1) B | ..] (columns of negative powers: zero)
+#pragma unroll
+    for (int a = 0; a < TX; ++a) X[a] = Bpl[0][a];
     sfor<0, NT>([&](auto Dc) {
         constexpr int D = decltype(Dc)::value;
         double acc[NTM];
@@ -172,62 +231,89 @@ __device__ __attribute__((noinline)) void r16_build_P(const SetupArgs p, long lo
         sfor<0, SPT>([&](auto pc) {
             constexpr int pp = decltype(pc)::value;
             constexpr int d = D * SPT + pp;
-            if constexpr (d > 0) X = mm4(At, X, d <= SPT - 1 ? Bpl[d <= SPT - 1 ? d : 0] : 0.0);
+            if constexpr (d > 0) {
+                double Xn[TX];
+#pragma unroll
+                for (int a = 0; a < TX; ++a) {
+                    double v = (d <= SPT - 1) ? Bpl[d <= SPT - 1 ? d : 0][a] : 0.0;
+#pragma unroll
+                    for (int k2 = 0; k2 < TX; ++k2) v = mm4(At[k2][a], X[k2], v);
+                    Xn[a] = v;
+                }
+#pragma unroll
+                for (int a = 0; a < TX; ++a) X[a] = Xn[a];
+            }
             if constexpr (LPI == 16) {
-                sfor<D, NT>([&](auto Ic) { constexpr int I = decltype(Ic)::value; acc[I] = mm4(ap[I][pp], X, acc[I]); });
+                sfor<D, NT>([&](auto Ic) {
+                    constexpr int I = decltype(Ic)::value;
+#pragma unroll
+                    for (int k2 = 0; k2 < TX; ++k2) acc[I] = mm4(ap[I][pp][k2], X[k2], acc[I]);
+                });
             } else {
-                sfor<D / 4, NTM>([&](auto mc) { constexpr int m = decltype(mc)::value; acc[m] = mm4(ap[m][pp], X, acc[m]); });
+                sfor<D / 4, NTM>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+#pragma unroll
+                    for (int k2 = 0; k2 < TX; ++k2) acc[m] = mm4(ap[m][pp][k2], X[k2], acc[m]);
+                });
             }
         });
         if constexpr (LPI == 16) {
-            sfor<D, NT>([&](auto Ic) { constexpr int I = decltype(Ic)::value; store_tile<n, PACKED>(Pp, dP, I, I - D, 2.0 * acc[I], true, r, c); });
+            sfor<D, NT>([&](auto Ic) { constexpr int I = decltype(Ic)::value; store_tile<T, PACKED>(Pp, dP, I, I - D, 2.0 * acc[I], true, r, c); });
         } else {
             sfor<D / 4, NTM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 const int I = 4 * m + g;
-                store_tile<n, PACKED>(Pp, dP, I, I - D, 2.0 * acc[m], I >= D && I < NT, r, c);
+                store_tile<T, PACKED>(Pp, dP, I, I - D, 2.0 * acc[m], I >= D && I < NT, r, c);
             });
         }
     });
     __syncthreads();
 }
 
-// The set-up.  Lg: LDS of block g's instance (LPI = 16) or of the one instance (LPI = 64); oP / oW: where P and W go in it (packed
-// lower triangle: index row (row + 1) / 2 + col; or full rows of stride n + 1, both triangles); oG: n NX doubles of scratch for G
-// (may alias P / W: they are written after G has been read back); oD: a dummy slot for predicated stores.
-// bg: the instance block g works on.  Lq / valid rows: where the lane's OWN instance (q = lane / LPI) reads its rows of G back.
+// The set-up.  Lg: LDS of block g's instance (LPI = 16) or of the one instance (LPI = 64); oW: where W goes in it (packed lower
+// triangle: index row (row + 1) / 2 + col; or full rows of stride n + 1, both triangles); oG: n NX doubles of scratch for G (may alias
+// P / W: they are written after G has been read back); oD: a dummy slot for predicated stores.
+// bg: the instance block g works on.  Lq: where the lane's OWN instance (q = lane / LPI) reads its rows of G back.
 // On return: W in LDS (a barrier has been passed), G[s][a] = row (i + LPI s) of G in registers.  P: r16_build_P, on demand.
 template <int NX, int NU, int N, int LPI, bool PACKED, int RB>
 __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg, wg::ldsd *Lg, wg::ldsd *Lq, int oW, int oG, int oD,
                                               double (&G)[RB][NX])
 {
     using T = SetupT<NX, NU, N, LPI>;
-    constexpr int n = T::n, NT = T::NT, SPT = T::SPT, NTM = T::NTM;
+    constexpr int n = T::n, NT = T::NT, SPT = T::SPT, NTM = T::NTM, TX = T::TX, NUP = T::NUP;
     const int lane = threadIdx.x, r = lane >> 4, c = lane & 3, g = (lane >> 2) & 3;
     wg::ldsd *Wp = Lg + oW, *Gs = Lg + oG;
     const int dW = oD - oW, dG = oD - oG;
-    // ---- the model and the weights as register matrices ----
+    // ---- the model and the weights as register matrices (tiles [a][b]: rows 4a.., columns 4b..) ----
     const ModelLd<NX, NU> ld{p, bg};
-    auto ldA = [&](int a, int k) -> double { return ld.A(a, k); };
-    auto ldB = [&](int a, int k) -> double { return ld.B(a, k); };
-    auto ldS = [&](int o, int a, int k, int dim) -> double { return ld.S(o, a, k, dim); };
-    const double A = ldA(r, c), Bp = ldB(r, c), Bt = ldB(c, r);
-    const double Q = ldS(p.oQ, r, c, NX), PT = ldS(p.oP, r, c, NX), Rp = ldS(p.oR, r, c, NU);
-    const double nBt = -Bt;
+    double A[TX][TX], Q[TX][TX], S[TX][TX];
+    double Bp[TX], nBt[TX];                                           // B (n_x x 4, columns 0..NU-1) by row tiles; -(B tile)' as register matrices
+    double Bpl[SPT][TX], nBpl[SPT][TX];                               // B (and -B) in column block q of a tile
+#pragma unroll
+    for (int a = 0; a < TX; ++a) {
+#pragma unroll
+        for (int b = 0; b < TX; ++b) {
+            A[a][b] = ld.A(4 * a + r, 4 * b + c);
+            Q[a][b] = ld.S(p.oQ, 4 * a + r, 4 * b + c, NX); S[a][b] = ld.S(p.oP, 4 * a + r, 4 * b + c, NX);
+        }
+        Bp[a] = ld.B(4 * a + r, c); nBt[a] = -ld.B(4 * a + c, r);
+#pragma unroll
+        for (int qq = 0; qq < SPT; ++qq) { Bpl[qq][a] = ld.B(4 * a + r, c - qq * NUP); nBpl[qq][a] = -Bpl[qq][a]; }
+    }
+    const double Rp = (r == c && r >= NU && r < NUP) ? 1.0 : ld.S(p.oR, r, c, NU);   // (a dummy input weighs 1)
 
     // ---- backward sweep: Riccati recursion, the rows rho_k, W by one update per column tile ----
     double Wacc[NTM][NT];                         // tile (I, J), J <= I: LPI = 16: Wacc[I][J]; LPI = 64: block g of Wacc[m][J] holds tile (4m+g, J)
-    double rho[NTM];                              // rho' of the rows of tile I (NX x 4: column = row of the tile)
-    double rho_r[(LPI == 64) ? NT : 1];           // LPI = 64: every tile's rho' in every block (the B operand of an update is one tile for all)
+    double rho[NTM][TX];                          // rho' of the rows of tile I (n_x x 4: column = row of the tile), by row tiles
+    double rho_r[(LPI == 64) ? NT : 1][TX];       // LPI = 64: every tile's rho' in every block (the B operand of an update is one tile for all)
     // T(:, M)' and (T(:, M) D_M^-1 / 2)' of the current column tile M on the rows of every tile from M on: register-matrix row
-    // q NU + u <-> column u of stage M SPT + q; filled stage by stage (the accumulator operand), used once per column tile
+    // q NUP + u <-> column u of stage M SPT + q; filled stage by stage (the accumulator operand), used once per column tile
     double TtA[NT], TDA[NTM];
-    double Bpl[SPT], nBpl[SPT];                   // B (and -B) in column block q of a tile
-#pragma unroll
-    for (int qq = 0; qq < SPT; ++qq) { Bpl[qq] = ldB(r, c - qq * NU); nBpl[qq] = -Bpl[qq]; }
 #pragma unroll
     for (int m = 0; m < NTM; ++m) {
-        rho[m] = 0.0; TDA[m] = 0.0;
+        TDA[m] = 0.0;
+#pragma unroll
+        for (int a = 0; a < TX; ++a) rho[m][a] = 0.0;
 #pragma unroll
         for (int J = 0; J < NT; ++J) Wacc[m][J] = 0.0;
     }
@@ -235,35 +321,103 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
     for (int J = 0; J < NT; ++J) TtA[J] = 0.0;
     if constexpr (LPI == 64) {
 #pragma unroll
-        for (int J = 0; J < NT; ++J) rho_r[J] = 0.0;
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int a = 0; a < TX; ++a) rho_r[J][a] = 0.0;
     }
-    double S = PT;
+    // o' = Acl' o (+ add) on an n_x x 4 column of tiles
+    auto advance = [&](double (&o)[TX], const double (&Acl)[TX][TX], const double (&add)[TX], bool with_add) {
+        double t[TX];
+#pragma unroll
+        for (int a = 0; a < TX; ++a) {
+            double v = with_add ? add[a] : 0.0;
+#pragma unroll
+            for (int k = 0; k < TX; ++k) v = mm4(Acl[k][a], o[k], v);
+            t[a] = v;
+        }
+#pragma unroll
+        for (int a = 0; a < TX; ++a) o[a] = t[a];
+    };
+    // (x)' o + cc with x, o columns of tiles: a 4 x 4 register matrix
+    auto dotc = [&](const double (&x)[TX], const double (&o)[TX], double cc) -> double {
+        double v = cc;
+#pragma unroll
+        for (int k = 0; k < TX; ++k) v = mm4(x[k], o[k], v);
+        return v;
+    };
     sfor<0, N>([&](auto jc) {
         constexpr int j = N - 1 - decltype(jc)::value;
-        constexpr int Ij = T::tile_of_stage(j), off = T::off_of_stage(j), q = off / NU;
+        constexpr int Ij = T::tile_of_stage(j), off = T::off_of_stage(j), q = off / NUP;
         constexpr bool first_of_tile = (j == N - 1) || (q == SPT - 1);        // (backward: the highest stage of column tile Ij comes first)
-        const double SA = mm4(S, A), SB = mm4(S, Bp);
-        const double F = mm4(Bp, SA), Re = mm4(Bp, SB, Rp);
-        const double R0 = small_inverse<NU>(Re, r, c);
-        const double K = mm4(R0, F);
-        const double Acl = mm4(nBt, K, A);
-        if constexpr (j > 0) {
-            const double Z = mm4(S, Acl);
-            S = mm4(A, Z, Q);
+        double SA[TX][TX], SB[TX], F[TX], K[TX], Acl[TX][TX], Ktp[TX], nBRt[TX];
+#pragma unroll
+        for (int a = 0; a < TX; ++a) {
+#pragma unroll
+            for (int b = 0; b < TX; ++b) {
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < TX; ++k) v = mm4(S[k][a], A[k][b], v);
+                SA[a][b] = v;
+            }
+            double w = 0.0;
+#pragma unroll
+            for (int k = 0; k < TX; ++k) w = mm4(S[k][a], Bp[k], w);
+            SB[a] = w;
         }
-        const double SH = (r < NU && c == off + r) ? 1.0 : 0.0;       // as a right factor: moves columns 0.. to off..; its transpose as a left factor: rows
-        const double Iq = (r == c && r >= off && r < off + NU) ? 1.0 : 0.0;   // the identity block of T(:, j), at the tile position of stage j
+        double Re = Rp;
+#pragma unroll
+        for (int k = 0; k < TX; ++k) Re = mm4(Bp[k], SB[k], Re);
+#pragma unroll
+        for (int b = 0; b < TX; ++b) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < TX; ++k) v = mm4(Bp[k], SA[k][b], v);
+            F[b] = v;
+        }
+        const double R0 = small_inverse<NUP>(Re, r, c);
+#pragma unroll
+        for (int b = 0; b < TX; ++b) K[b] = mm4(R0, F[b]);
+#pragma unroll
+        for (int a = 0; a < TX; ++a)
+#pragma unroll
+            for (int b = 0; b < TX; ++b) Acl[a][b] = mm4(nBt[a], K[b], A[a][b]);
+        if constexpr (j > 0) {
+            double Zm[TX][TX];
+#pragma unroll
+            for (int a = 0; a < TX; ++a)
+#pragma unroll
+                for (int b = 0; b < TX; ++b) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int k = 0; k < TX; ++k) v = mm4(S[k][a], Acl[k][b], v);
+                    Zm[a][b] = v;
+                }
+#pragma unroll
+            for (int a = 0; a < TX; ++a)
+#pragma unroll
+                for (int b = 0; b < TX; ++b) {
+                    double v = Q[a][b];
+#pragma unroll
+                    for (int k = 0; k < TX; ++k) v = mm4(A[k][a], Zm[k][b], v);
+                    S[a][b] = v;
+                }
+        }
+        const double SH = (r < NUP && c == off + r) ? 1.0 : 0.0;       // as a right factor: moves columns 0.. to off..; its transpose as a left factor: rows
+        const double Iq = (r == c && r >= off && r < off + NUP) ? 1.0 : 0.0;   // the identity block of T(:, j), at the tile position of stage j
         const double R0h = 0.5 * R0;
-        const double Ktp = mm4(K, SH);                                // K' in the columns of stage j
         const double R1h = (off == 0) ? R0h : mm4(R0h, SH);           // Re^-1 / 2, columns moved to stage j's
         const double Rqq = (off == 0) ? R0h : mm4(SH, R1h);           // ... and rows
-        const double nBRt = mm4(nBt, R1h);                            // -(1/2) B Re^-1 in the columns of stage j
+#pragma unroll
+        for (int a = 0; a < TX; ++a) {
+            Ktp[a] = mm4(K[a], SH);                                   // K' in the columns of stage j
+            nBRt[a] = mm4(nBt[a], R1h);                               // -(1/2) B Re^-1 in the columns of stage j
+        }
         if constexpr (LPI == 16) {
             sfor<Ij, NT>([&](auto Ic) {
                 constexpr int I = decltype(Ic)::value;
                 const double cT = (first_of_tile ? 0.0 : TtA[I]) + (I == Ij ? Iq : 0.0);
                 const double cD = (first_of_tile ? 0.0 : TDA[I]) + (I == Ij ? Rqq : 0.0);
-                if constexpr (T::live(I, j)) { TtA[I] = mm4(nBpl[q], rho[I], cT); TDA[I] = mm4(nBRt, rho[I], cD); }
+                if constexpr (T::live(I, j)) { TtA[I] = dotc(nBpl[q], rho[I], cT); TDA[I] = dotc(nBRt, rho[I], cD); }
                 else { TtA[I] = cT; TDA[I] = cD; }                  // (I == Ij and no row of a later stage in the tile yet)
             });
             if constexpr (q == 0) {
@@ -277,21 +431,24 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
             }
             sfor<Ij, NT>([&](auto Ic) {
                 constexpr int I = decltype(Ic)::value;
-                if constexpr (T::live(I, j)) rho[I] = mm4(Acl, rho[I], I == Ij ? Ktp : 0.0);
-                else rho[I] = Ktp;
+                if constexpr (T::live(I, j)) advance(rho[I], Acl, Ktp, I == Ij);
+                else {
+#pragma unroll
+                    for (int a = 0; a < TX; ++a) rho[I][a] = Ktp[a];
+                }
             });
         } else {
             constexpr int m0 = Ij / 4;
             sfor<Ij, NT>([&](auto Jc) {
                 constexpr int J = decltype(Jc)::value;
                 const double cT = (first_of_tile ? 0.0 : TtA[J]) + (J == Ij ? Iq : 0.0);
-                if constexpr (T::live(J, j)) TtA[J] = mm4(nBpl[q], rho_r[J], cT);
+                if constexpr (T::live(J, j)) TtA[J] = dotc(nBpl[q], rho_r[J], cT);
                 else TtA[J] = cT;
             });
             sfor<m0, NTM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 const bool mine = (4 * m + g == Ij);
-                TDA[m] = mm4(nBRt, rho[m], (first_of_tile ? 0.0 : TDA[m]) + (mine ? Rqq : 0.0));
+                TDA[m] = dotc(nBRt, rho[m], (first_of_tile ? 0.0 : TDA[m]) + (mine ? Rqq : 0.0));
             });
             if constexpr (q == 0) {
                 sfor<Ij, NT>([&](auto Jc) {
@@ -305,22 +462,29 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
             sfor<m0, NTM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 const bool mine = (4 * m + g == Ij);
-                rho[m] = mm4(Acl, rho[m], mine ? Ktp : 0.0);
+                double add[TX];
+#pragma unroll
+                for (int a = 0; a < TX; ++a) add[a] = mine ? Ktp[a] : 0.0;
+                advance(rho[m], Acl, add, true);
             });
             sfor<Ij, NT>([&](auto Jc) {
                 constexpr int J = decltype(Jc)::value;
-                if constexpr (T::live(J, j)) rho_r[J] = mm4(Acl, rho_r[J], J == Ij ? Ktp : 0.0);
-                else rho_r[J] = Ktp;
+                if constexpr (T::live(J, j)) advance(rho_r[J], Acl, Ktp, J == Ij);
+                else {
+#pragma unroll
+                    for (int a = 0; a < TX; ++a) rho_r[J][a] = Ktp[a];
+                }
             });
         }
     });
 
-    // ---- G: rho' (NX x 4 per tile: lane (r, c) holds rho[row 4I + c][state r]) -> rows, through LDS ----
+    // ---- G: rho' (n_x x 4 per tile: lane (r, c) of row tile a holds rho[row 4I + c][state 4a + r]) -> rows, through LDS ----
 #pragma unroll
     for (int m = 0; m < NTM; ++m) {
         const int I = (LPI == 16) ? m : 4 * m + g;
-        const int row = 4 * I + c;
-        Gs[(r < NX && row < n) ? row * NX + r : dG] = -rho[m];
+        const int row = T::row_of(4 * I + c);
+#pragma unroll
+        for (int a = 0; a < TX; ++a) Gs[(4 * a + r < NX && row >= 0) ? row * NX + 4 * a + r : dG] = -rho[m][a];
     }
     __syncthreads();
     {
@@ -344,7 +508,7 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
 #pragma unroll
         for (int J = 0; J < NT; ++J) {
             const int I = (LPI == 16) ? m : 4 * m + g;
-            if ((LPI == 16) ? (J <= m) : (J <= 4 * m + 3)) store_tile<n, PACKED>(Wp, dW, I, J, Wacc[m][J], I < NT && J <= I, r, c);
+            if ((LPI == 16) ? (J <= m) : (J <= 4 * m + 3)) store_tile<T, PACKED>(Wp, dW, I, J, Wacc[m][J], I < NT && J <= I, r, c);
         }
     __syncthreads();
 }

@@ -337,7 +337,7 @@ def test_difficulty_ordering_is_transparent(solver, golden_dir):
 # ---------------- stress: random shapes of cost, box, conditioning on the specialised shapes ----------------
 WG_SHAPES = [(8, 4, 30), (6, 3, 15), (16, 2, 17), (3, 2, 64), (5, 1, 33)]     # n = 120, 45, 34, 128, 33
 PREBUILT = [(4, 2, 10), (2, 1, 10), (2, 1, 5), (2, 1, 7), (2, 1, 20), (2, 1, 30), (4, 2, 20)]
-JIT_MAX_NX, JIT_MAX_NU = 4, 2              # lqmpc_r16_setup.h: SETUP_MAX_NX / SETUP_MAX_NU
+JIT_MAX_NX, JIT_MAX_NU = 8, 4              # lqmpc_r16_setup.h: SETUP_MAX_NX / SETUP_MAX_NU
 
 
 def jit_domain(nx, nu, N):
@@ -598,7 +598,8 @@ def test_ordered_rollout_growing_batch_on_one_handle(golden_dir):
         s.close(); s2.close()
 
 
-@pytest.mark.parametrize("nx,nu,N", [(3, 2, 6), (1, 1, 1), (2, 1, 12), (4, 2, 12), (3, 1, 10), (4, 2, 16), (4, 2, 24), (2, 1, 40)])
+@pytest.mark.parametrize("nx,nu,N", [(3, 2, 6), (1, 1, 1), (2, 1, 12), (4, 2, 12), (3, 1, 10), (4, 2, 16), (4, 2, 24), (2, 1, 40),
+                                     (5, 3, 4), (8, 4, 8), (6, 3, 15), (7, 2, 9), (3, 3, 5), (8, 1, 48)])
 def test_run_time_compiled_shapes(solver, nx, nu, N):
     """Shapes without a prebuilt instantiation get the 16-lane-row kernel compiled at run time (lqmpc_jit.hip; utils_class.py:23, 62:
     the reference takes any N): every entry point, the ordered walk (probe compiled too), the hand-back to the generic kernel over
