@@ -425,6 +425,29 @@ def main():
                          "note": "A, B, x0 of the headline batch from pinned host memory, J_T back; HIP events, best of 4; "
                                  "value_pcie_inclusive = QP-steps / (h2d + one launch + d2h), reported beside `value`, never as it"}
         del tA, tB, tx
+        # a shape WITHOUT a prebuilt instantiation beside its tabled neighbour: the 16-lane-row kernel compiled at run time
+        # (lqmpc_jit.hip; rounds 1-2 dropped such shapes onto the generic kernel, 650x slower)
+        if args.config in (3, 4):
+            Nj = N + 2
+            bj = synth.make_batch(args.config, Bsz=Bsz, fixture_dir=gold)
+            try:
+                t0 = time.perf_counter()
+                s.rollout_batch_dev(nx, nu, Nj, Bsz, T, dA, dB, *shared, dx0, b["A_true"], b["B_true"], dJT, dstatus=dst, diters=dit)
+                torch.cuda.synchronize()
+                first_s = time.perf_counter() - t0
+                dtj, kmsj, vj = run(lambda: s.rollout_batch_dev(nx, nu, Nj, Bsz, T, dA, dB, *shared, dx0, b["A_true"], b["B_true"], dJT,
+                                                                dstatus=dst, diters=dit), max(args.steps // 2, 5), 2, qp_local)
+                itj, bad_j = totals()
+                extra["untabled_shape"] = {"shape": [nx, nu, Nj], "value": round(vj, 1), "unit": "QP-steps/s",
+                                           "kernel_ms_per_launch": round(kmsj, 4), "kernel": s.last_kernel(), "iters_mean": round(itj / qp_local, 3),
+                                           "status_nonzero": bad_j, "first_call_s": round(first_s, 3),
+                                           "tabled_neighbour": {"shape": [nx, nu, N], "kernel_ms_per_launch": round(kernel_ms, 4)},
+                                           "ratio_to_tabled_neighbour": round(kmsj / kernel_ms, 3),
+                                           "workload": "the headline batch with horizon N + 2 (no prebuilt instantiation): run-time compiled "
+                                                       "16-lane-row kernel; first_call_s includes the compile unless the code object was cached"}
+            except Exception as e:
+                extra["untabled_shape"] = {"error": repr(e)}
+            del bj
         # closed-loop rollouts of small batches: us per MPC step (the reference runs ONE system per simulate(), utils_class.py:245-285)
         small = {}
         for m in (1, 64, 4096):
