@@ -372,7 +372,7 @@ def main():
                               "workload": "lqmpc_sweep_batch_dev: max V_N over 8 level-set points + the T-step rollout per system "
                                           "(utils_class.py:813-833), one launch"}
         # the rest of data_generation per system (utils_class.py:837-859): dlqr + energy_decreasing + energy_bound on the GPU
-        if args.config != 1 and n <= 40:                   # (the Jacobi sweeps grow with n^3: the n = 120 shape takes a minute per launch)
+        if args.config != 1:
             dMV = torch.full((Bsz,), 0.5, dtype=torch.float64, device=dev)
             dlev = torch.full((Bsz,), 5e-3, dtype=torch.float64, device=dev)
             outs = [torch.empty(Bsz, dtype=torch.float64, device=dev) for _ in range(5)]
@@ -390,8 +390,11 @@ def main():
             msb = s.timer_end() / 3
             extra["bounds"] = {"value": round(Bsz / (msb * 1e-3), 1), "unit": "systems/s", "kernel_ms_per_launch": round(msb, 4),
                                "dlqr_not_converged": int((dstb == 1).sum().item()) + int((dstb == 2).sum().item()),
+                               "kernel": s.last_kernel(),
                                "workload": "lqmpc_bounds_batch_dev: dlqr (doubling) + local radius + stability numbers + alpha/beta/xi/eta/bound "
-                                           "per system (utils_class.py:837-859), one instance per lane; Householder tridiagonalisation + bisection for the two N n_u x N n_u eigenproblems"}
+                                           "per system (utils_class.py:837-859); on chip: n_x x n_x work on the matrix core (four systems per "
+                                           "wavefront), Gamma'Gamma from the Toeplitz form, Householder tridiagonalisation by rows in LDS, "
+                                           "extreme eigenvalues by multisection on the Sturm count"}
         if args.config != 1:
             # the engine north_star names, alone: Mehrotra interior point + active-set polish, no warm start, no presolve shortcut
             # beyond the default (options.warm_start = 0)

@@ -152,6 +152,8 @@ int lqmpc_get_options(const lqmpc_handle *h, lqmpc_options *opt);
  * compiler's message in `log` if given. */
 int lqmpc_jit_cache_dir(const char *dir);
 int lqmpc_jit_compile(int nx, int nu, int N, char *log, int log_len);
+/* ... and the two on-chip kernels of lqmpc_bounds_batch for a shape (returns 2). */
+int lqmpc_jit_compile_bounds(int nx, int nu, int N, char *log, int log_len);
 
 /* 1 if a register-resident specialisation for (nx,nu,N) is compiled in, else 0. */
 int lqmpc_has_specialization(int nx, int nu, int N);

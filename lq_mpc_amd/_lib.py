@@ -28,7 +28,7 @@ EXPORTS = [
     "lqmpc_sweep_batch", "lqmpc_sweep_batch_dev",
     "lqmpc_bounds_batch", "lqmpc_bounds_batch_dev",
     "lqmpc_timer_begin", "lqmpc_timer_end",
-    "lqmpc_jit_cache_dir", "lqmpc_jit_compile",
+    "lqmpc_jit_cache_dir", "lqmpc_jit_compile", "lqmpc_jit_compile_bounds",
 ]
 
 
@@ -102,6 +102,7 @@ def lib():
     L.lqmpc_timer_end.argtypes = [_H, ctypes.POINTER(ctypes.c_float)]
     L.lqmpc_jit_cache_dir.argtypes = [ctypes.c_char_p]
     L.lqmpc_jit_compile.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+    L.lqmpc_jit_compile_bounds.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
     # code objects of run-time compiled shapes are kept next to the library (falls back to memory only if not writable)
     L.lqmpc_jit_cache_dir(JIT_CACHE.encode())
     _lib = L
@@ -114,6 +115,15 @@ def jit_compile(nx, nu, N):
     rc = lib().lqmpc_jit_compile(int(nx), int(nu), int(N), log, len(log))
     if rc < 0:
         raise LqmpcError(f"lqmpc_jit_compile({nx},{nu},{N}) -> {rc}: {log.value.decode(errors='replace')}")
+    return rc
+
+
+def jit_compile_bounds(nx, nu, N):
+    """The two on-chip kernels of bounds_batch for one shape, compiled (or found in the cache) now; needs no GPU."""
+    log = ctypes.create_string_buffer(4096)
+    rc = lib().lqmpc_jit_compile_bounds(int(nx), int(nu), int(N), log, len(log))
+    if rc < 0:
+        raise LqmpcError(f"lqmpc_jit_compile_bounds({nx},{nu},{N}) -> {rc}: {log.value.decode(errors='replace')}")
     return rc
 
 

@@ -32,6 +32,7 @@ bool launch_wg(const KParams &p, hipStream_t stream, const char **name);
 bool jit_r16_shape(int nx, int nu, int N, int *lpi);
 bool jit_available(int device, int nx, int nu, int N, int mode, std::string *why);
 bool launch_jit(int device, const KParams &p, hipStream_t stream, const char **name, std::string *why);
+bool launch_jit_bounds(int device, const BoundsParams &p, hipStream_t stream, std::string *why);
 // lqmpc_generic.hip: the generic kernel over a device-side list (p.perm, p.count_dev) with `cols` workspace columns
 void launch_generic_list(const KParams &p, int cols, hipStream_t stream);
 }  // namespace lqmpc
@@ -960,16 +961,41 @@ int lqmpc_bounds_batch_dev(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, 
     for (int k = 0; k < nu; ++k) { bar_u += std::max(lb[k] * lb[k], ub[k] * ub[k]); bar_du += (ub[k] - lb[k]) * (ub[k] - lb[k]); }
     const double sc[7] = {qmax, qmin, rmax, rmin, V_expert, bar_u, bar_du};
     bp.osc = put(sc, 7);
+    // for the on-chip kernels: identity / zero weights (Gamma'Gamma is the condensed Hessian with them), and whether Q, R are multiples of I
+    std::vector<double> eye((size_t)nx * nx, 0.0), zer((size_t)nu * nu, 0.0);
+    for (int a = 0; a < nx; ++a) eye[(size_t)a * nx + a] = 1.0;
+    bp.oI = put(eye.data(), nx * nx); bp.oZ = put(zer.data(), nu * nu);
+    auto scalar_mult = [](const double *M, int n) { for (int a = 0; a < n; ++a) for (int c = 0; c < n; ++c) if (M[a * n + c] != (a == c ? M[0] : 0.0)) return false; return true; };
+    bp.q_scalar = scalar_mult(Q, nx) ? 1 : 0; bp.r_scalar = scalar_mult(R, nu) ? 1 : 0;
+    bp.qs = Q[0]; bp.rs = R[0];
     rc = ensure(h, h->shared, std::max(sh.size(), (size_t)8192) * sizeof(double));
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h->shared.p, sh.data(), sh.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->shared_host.clear();                              // the solver's cached copy of the shared block is gone
+    bp.o = lqmpc::bounds_offsets(nx, nu, N);
     bp.nx = nx; bp.nu = nu; bp.N = N; bp.Bsz = Bsz;
     bp.A = dA; bp.B = dB; bp.eA = de_A; bp.eB = de_B; bp.MV = dMV; bp.sh = (const double *)h->shared.p;
-    bp.o = lqmpc::bounds_offsets(nx, nu, N);
     bp.K = dK; bp.alpha = dalpha; bp.beta = dbeta; bp.xi = dxi; bp.eta = deta; bp.bound = dbound; bp.eps = deps; bp.aux = daux;
     bp.status = dstatus;
+    // the on-chip kernels (registers + LDS, two launches): prebuilt for the reference's shapes, compiled at run time for the others;
+    // the HBM-workspace kernel below stays for what neither serves (kernel = generic forces it)
+    if (h->opt.kernel != LQMPC_KERNEL_GENERIC) {
+        rc = ensure(h, h->ws, (size_t)Bsz * 10 * sizeof(double));
+        if (rc) return rc;
+        bp.rec = (double *)h->ws.p; bp.b0 = 0; bp.b1 = Bsz;
+        bool done = lqmpc::launch_bounds_chip(bp, h->stream);
+        if (!done && h->opt.jit != 0) {
+            std::string why;
+            done = lqmpc::launch_jit_bounds(h->device, bp, h->stream, &why);
+            if (!done) g_err = "on-chip bounds kernels unavailable, using the workspace kernel: " + why;
+        }
+        if (done) {
+            HIP_TRY(hipGetLastError());
+            h->last_kernel = "lqmpc_bounds_small_kernel + lqmpc_bounds_big_kernel";
+            return 0;
+        }
+    }
     // workspace: at most ~1 GiB at a time, the batch in chunks of whole wavefronts
     const size_t per = (size_t)bp.o.total * sizeof(double);
     long long chunk = (long long)(((size_t)1 << 30) / per) / 64 * 64;

@@ -20,6 +20,7 @@
 // one is not: the closed loop is A + B K as a matrix product (utils.py:356 multiplies elementwise, the same thing for n_u = 1).
 #include "lqmpc_common.h"
 #include "lqmpc_bounds.h"
+#include "lqmpc_bounds_chip.h"
 
 namespace lqmpc {
 
@@ -480,6 +481,35 @@ __global__ void __launch_bounds__(64) lqmpc_bounds_kernel(BoundsParams p)
         a[4 * Bsz + b] = nG; a[5 * Bsz + b] = nPhi; a[6 * Bsz + b] = min_H; a[7 * Bsz + b] = nK;
     }
     if (p.status) p.status[b] = status;
+}
+
+// ---------------- the on-chip kernels (lqmpc_bounds_chip.h), prebuilt for the reference's shapes and the headline shape ----------------
+template <int NX, int NU, int N>
+__global__ void __launch_bounds__(64) lqmpc_bounds_small_kernel(BoundsParams p) { bounds_small<NX, NU, N>(p); }
+
+template <int NX, int NU, int N, int LPI>
+__global__ void __launch_bounds__(64) lqmpc_bounds_big_kernel(BoundsParams p)
+{
+    __shared__ double lds_raw[BigT<NX, NU, N, LPI>::IPW * BigT<NX, NU, N, LPI>::INST];
+    bounds_big<NX, NU, N, LPI>(p, lds_raw);
+}
+
+template <int NX, int NU, int N>
+static void launch_chip_one(const BoundsParams &p, hipStream_t stream)
+{
+    constexpr int LPI = (N * NU <= 32) ? 16 : 64, IPW = 64 / LPI;
+    const long long m = p.b1 - p.b0;
+    hipLaunchKernelGGL((lqmpc_bounds_small_kernel<NX, NU, N>), dim3((unsigned)((m + 3) / 4)), dim3(64), 0, stream, p);
+    hipLaunchKernelGGL((lqmpc_bounds_big_kernel<NX, NU, N, LPI>), dim3((unsigned)((m + IPW - 1) / IPW)), dim3(64), 0, stream, p);
+}
+
+bool launch_bounds_chip(const BoundsParams &p, hipStream_t stream)
+{
+#define LQMPC_BC(X_, U_, H_) if (p.nx == X_ && p.nu == U_ && p.N == H_) { launch_chip_one<X_, U_, H_>(p, stream); return true; }
+    LQMPC_BC(2, 1, 6) LQMPC_BC(2, 1, 7) LQMPC_BC(2, 1, 8) LQMPC_BC(2, 1, 9) LQMPC_BC(2, 1, 10)      // the reference's horizon sweep
+    LQMPC_BC(4, 2, 10)                                                                          // C3
+#undef LQMPC_BC
+    return false;
 }
 
 void launch_bounds(const BoundsParams &p, hipStream_t stream)

@@ -9,6 +9,7 @@
 // The compile itself needs no GPU (lqmpc_jit_compile can pre-build code objects on a build machine).
 #include "lqmpc_common.h"
 #include "lqmpc_r16_body.h"        // (host side: the LDS-size arithmetic of R16 is checked against the templates below)
+#include "lqmpc_bounds_chip.h"
 #include "../../include/lqmpc.h"
 
 #include <hip/hiprtc.h>
@@ -33,6 +34,7 @@ namespace lqmpc {
 //   an active-set system has <= 16 unknowns: one per lane), 32 < n <= 48 with one instance per wavefront (<= 24 unknowns).
 bool jit_r16_shape(int nx, int nu, int N, int *lpi)
 {
+    if (lpi) *lpi = 0;
     if (nx < 1 || nu < 1 || N < 1 || nx > SETUP_MAX_NX || nu > SETUP_MAX_NU) return false;
     const int n = N * nu;
     if (n > 48) return false;
@@ -116,9 +118,32 @@ static unsigned long long fnv(const std::string &s, unsigned long long h = 14695
     return h;
 }
 
+constexpr int JIT_BOUNDS_SMALL = 100, JIT_BOUNDS_BIG = 101;      // cache keys beside the solver's modes
+
+// BigT<NX, NU, N, LPI>::INST restated for run-time dimensions
+static int bounds_big_inst(int nx, int nu, int N, int lpi)
+{
+    const int n = N * nu, rb = (n + lpi - 1) / lpi, vec = lpi * rb;
+    return n * (n + 1) + 4 * vec + N * nx * nu + 2 + 2;
+}
+static_assert(BigT<4, 2, 10, 16>::INST == 20 * 21 + 4 * 32 + 80 + 4 && BigT<2, 1, 6, 16>::INST == 6 * 7 + 4 * 16 + 12 + 4, "bounds_big_inst() restates this");
+
 static std::string program_text(int nx, int nu, int N, int mode)
 {
     char buf[1024];
+    if (mode == JIT_BOUNDS_SMALL) {
+        snprintf(buf, sizeof buf,
+                 "#include \"lqmpc_bounds_chip.h\"\nnamespace lqmpc {\nextern \"C\" __global__ void __launch_bounds__(64) lqmpc_jit_kernel(BoundsParams p)\n"
+                 "{ bounds_small<%d, %d, %d>(p); }\n}\n", nx, nu, N);
+        return buf;
+    }
+    if (mode == JIT_BOUNDS_BIG) {
+        const int lpi = N * nu <= 32 ? 16 : 64;
+        snprintf(buf, sizeof buf,
+                 "#include \"lqmpc_bounds_chip.h\"\nnamespace lqmpc {\nextern \"C\" __global__ void __launch_bounds__(64) lqmpc_jit_kernel(BoundsParams p)\n"
+                 "{ extern __shared__ double lds_dyn[]; bounds_big<%d, %d, %d, %d>(p, lds_dyn); }\n}\n", nx, nu, N, lpi);
+        return buf;
+    }
     if (mode == MODE_PROBE) {
         snprintf(buf, sizeof buf,
                  "#include \"lqmpc_probe.h\"\nnamespace lqmpc {\nextern \"C\" __global__ void __launch_bounds__(64) lqmpc_jit_kernel(KParams p)\n"
@@ -138,7 +163,15 @@ static std::string cache_path(const std::string &text)
 {
     if (g_dir.empty()) return "";
     unsigned long long h = fnv(text);
-    for (int i = 0; i < k_jit_count; ++i) h = fnv(k_jit_srcs[i], h);
+    // (only the headers the program includes enter the key: an edit of the bounds kernels leaves the cached solver kernels valid)
+    const bool bounds = text.find("lqmpc_bounds_chip.h") != std::string::npos, probe = text.find("lqmpc_probe.h") != std::string::npos;
+    for (int i = 0; i < k_jit_count; ++i) {
+        const std::string nm = k_jit_names[i];
+        const bool used = nm == "lqmpc_common.h" || (probe ? nm == "lqmpc_probe.h"
+                          : (nm == "lqmpc_wg_linalg.h" || nm == "lqmpc_r16_setup.h" ||
+                             (bounds ? (nm == "lqmpc_bounds.h" || nm == "lqmpc_bounds_chip.h") : nm == "lqmpc_r16_body.h")));
+        if (used) h = fnv(k_jit_srcs[i], h);
+    }
     int maj = 0, min = 0;
     if (g_rtc.version) g_rtc.version(&maj, &min);
     h = fnv(std::to_string(maj) + "." + std::to_string(min) + " gfx950 O3", h);
@@ -222,7 +255,7 @@ static const Loaded *get_kernel(int device, int nx, int nu, int N, int mode, std
         err = g_failed[Key{nx, nu, N, mode}] = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
         return nullptr;
     }
-    if (!g_names.count(Key{nx, nu, N, 0})) {
+    if (mode < JIT_BOUNDS_SMALL && !g_names.count(Key{nx, nu, N, 0})) {
         char nm[96];
         const Build b = r16_build(nx, nu, N);
         snprintf(nm, sizeof nm, "lqmpc_r%d_jit_kernel<%d,%d,%d>", b.lpi, nx, nu, N);
@@ -265,6 +298,36 @@ bool launch_jit(int device, const KParams &p, hipStream_t stream, const char **n
 
 int jit_lanes(int nx, int nu, int N) { int l = 0; return jit_r16_shape(nx, nu, N, &l) ? l : 0; }
 
+// the on-chip pair of bound-coefficient kernels (lqmpc_bounds_chip.h) of a shape without prebuilt ones: nx <= 8, nu <= 4, any N nu <= 128
+bool jit_bounds_shape(int nx, int nu, int N)
+{
+    if (nx < 1 || nu < 1 || N < 1 || nx > SETUP_MAX_NX || nu > SETUP_MAX_NU || N * nu > 128) return false;
+    const int lpi = N * nu <= 32 ? 16 : 64;
+    return (long long)(64 / lpi) * bounds_big_inst(nx, nu, N, lpi) * 8 <= 160 * 1024;
+}
+
+bool launch_jit_bounds(int device, const BoundsParams &p, hipStream_t stream, std::string *why)
+{
+    std::string err;
+    if (!jit_bounds_shape(p.nx, p.nu, p.N)) { if (why) *why = "outside the domain of the on-chip bounds kernels"; return false; }
+    const Loaded *k1 = get_kernel(device, p.nx, p.nu, p.N, JIT_BOUNDS_SMALL, err);
+    const Loaded *k2 = k1 ? get_kernel(device, p.nx, p.nu, p.N, JIT_BOUNDS_BIG, err) : nullptr;
+    if (!k1 || !k2) { if (why) *why = err; return false; }
+    const int lpi = p.N * p.nu <= 32 ? 16 : 64, ipw = 64 / lpi;
+    const size_t lds = (size_t)ipw * bounds_big_inst(p.nx, p.nu, p.N, lpi) * 8;
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void *)k2->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { if (why) *why = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); return false; }
+    }
+    BoundsParams arg = p;
+    void *args[] = {&arg};
+    const long long m = p.b1 - p.b0;
+    hipError_t e = hipModuleLaunchKernel(k1->fn, (unsigned)((m + 3) / 4), 1, 1, 64, 1, 1, 0, stream, args, nullptr);
+    if (e == hipSuccess) e = hipModuleLaunchKernel(k2->fn, (unsigned)((m + ipw - 1) / ipw), 1, 1, 64, 1, 1, (unsigned)lds, stream, args, nullptr);
+    if (e != hipSuccess) { if (why) *why = std::string("hipModuleLaunchKernel: ") + hipGetErrorString(e); return false; }
+    return true;
+}
+
 }  // namespace lqmpc
 
 extern "C" {
@@ -299,6 +362,22 @@ int lqmpc_jit_compile(int nx, int nu, int N, char *log, int log_len)
         }
     }
     return count;
+}
+
+// ... and the pair of on-chip bound-coefficient kernels of a shape (nx <= 8, nu <= 4, LDS image within 160 KiB); returns 2
+int lqmpc_jit_compile_bounds(int nx, int nu, int N, char *log, int log_len)
+{
+    if (log && log_len > 0) log[0] = '\0';
+    if (!lqmpc::jit_bounds_shape(nx, nu, N)) return LQMPC_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(lqmpc::g_mu);
+    for (int mode : {lqmpc::JIT_BOUNDS_SMALL, lqmpc::JIT_BOUNDS_BIG}) {
+        std::string err;
+        if (!lqmpc::get_code(nx, nu, N, mode, err)) {
+            if (log && log_len > 0) snprintf(log, (size_t)log_len, "bounds kernel %d: %s", mode - lqmpc::JIT_BOUNDS_SMALL, err.c_str());
+            return LQMPC_ERR_UNSUPPORTED;
+        }
+    }
+    return 2;
 }
 
 }  // extern "C"

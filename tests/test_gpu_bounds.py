@@ -26,6 +26,20 @@ def rel(a, b):
     return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))
 
 
+CHIP = "lqmpc_bounds_small_kernel + lqmpc_bounds_big_kernel"     # registers + LDS (prebuilt or compiled at run time); the default
+WORKSPACE = "lqmpc_bounds_kernel"                                # one instance per lane, matrices in an HBM workspace (kernel = generic)
+
+
+@pytest.fixture(params=[CHIP, WORKSPACE], ids=["chip", "workspace"])
+def bsolver(request, solver):
+    """both implementations of lqmpc_bounds_batch"""
+    from lq_mpc_amd import KERNEL_GENERIC, KERNEL_AUTO
+    solver.set_options(kernel=KERNEL_GENERIC if request.param == WORKSPACE else KERNEL_AUTO)
+    solver.expected_bounds_kernel = request.param
+    yield solver
+    solver.set_options(kernel=KERNEL_AUTO)
+
+
 def host_reference(N, A, B, Q, R, lb, ub, eA, eB, MV, x, p, V):
     F_u = np.vstack([np.diag(1.0 / ub), np.diag(1.0 / lb)])
     out = {k: [] for k in ("alpha", "beta", "xi", "eta", "bound", "eps", "K", "gamma", "rho_cl", "norm_Gamma", "norm_Phi", "min_eig_H")}
@@ -49,7 +63,8 @@ def host_reference(N, A, B, Q, R, lb, ub, eA, eB, MV, x, p, V):
     return {k: np.array(v) for k, v in out.items()}
 
 
-def test_reference_systems_against_host_oracle_and_npz(solver, golden_dir):
+def test_reference_systems_against_host_oracle_and_npz(bsolver, golden_dir):
+    solver = bsolver
     """The reference's 1 000 perturbed systems at N = 7 (utils_class.py:802-859): every coefficient against the host oracle, and
     the four tables of the npz (M_V from the GPU's own max-V_N pass, as in data_generation)."""
     d = np.load(os.path.join(golden_dir, "data_lq_mpc_multipleSys.npz"))
@@ -66,6 +81,7 @@ def test_reference_systems_against_host_oracle_and_npz(solver, golden_dir):
     MV = solver.max_vn_batch(7, A, B, Q2, R1, Q2, lb, ub, x0_vec)["M_V"]
     lev = np.tile(d["error"], 100)                                      # instance (j, i) has error level error[i]
     g = solver.bounds_batch(7, A, B, Q2, R1, lb, ub, lev, lev, MV, xs, P3, V, want_aux=True)
+    assert solver.last_kernel() == solver.expected_bounds_kernel
     assert np.all(g["status"] == 0)
     for k, name in (("xi", "xi_table_error"), ("alpha", "alpha_table_error"), ("beta", "beta_table_error"), ("bound", "bound_table_error")):
         np.testing.assert_allclose(g[k].reshape(100, 10), d[name], rtol=1e-8, err_msg=name)
@@ -77,7 +93,9 @@ def test_reference_systems_against_host_oracle_and_npz(solver, golden_dir):
 
 
 @pytest.mark.parametrize("nx,nu,N,Bsz", [(4, 2, 10, 300), (3, 3, 5, 130), (8, 4, 12, 70), (2, 1, 30, 64), (5, 2, 1, 40)])
-def test_random_systems_dense_weights(solver, nx, nu, N, Bsz):
+@pytest.mark.parametrize("weights", ["dense", "scalar_Q", "scalar"])
+def test_random_systems_dense_weights(bsolver, nx, nu, N, Bsz, weights):
+    solver = bsolver
     """Random stabilisable models, dense SPD Q and R (exercises the Kronecker ordering of hat H, utils.py:316-319), asymmetric box,
     per-instance error levels and energy bars."""
     rng = np.random.default_rng(10 * nx + nu + N)
@@ -88,13 +106,17 @@ def test_random_systems_dense_weights(solver, nx, nu, N, Bsz):
         M = rng.standard_normal((m, m)); M = M @ M.T / m + np.eye(m)
         return M * rng.uniform(lo, hi)
     Q, R = spd(nx, 0.5, 3.0), spd(nu, 0.2, 2.0)
+    if weights != "dense":                   # Q = q I: hat H = kron(R, I) + q Gamma'Gamma; R = r I as well: no second eigenproblem on the chip
+        Q = 1.7 * np.eye(nx)
+    if weights == "scalar":
+        R = 0.6 * np.eye(nu)
     lb, ub = -rng.uniform(0.05, 0.5, nu), rng.uniform(0.05, 0.5, nu)
     eA, eB = rng.uniform(1e-3, 1e-2, Bsz), rng.uniform(1e-3, 1e-2, Bsz)
     MV = rng.uniform(0.1, 5.0, Bsz)
     x, p, V = rng.standard_normal(nx) * 0.2, np.array([0.3, 1.5, 0.7]), 1.7
     A, B = np.ascontiguousarray(A), np.ascontiguousarray(B)
     g = solver.bounds_batch(N, A, B, Q, R, lb, ub, eA, eB, MV, x, p, V, want_aux=True)
-    assert solver.last_kernel() == "lqmpc_bounds_kernel"
+    assert solver.last_kernel() == solver.expected_bounds_kernel
     h = host_reference(N, A, B, Q, R, lb, ub, eA, eB, MV, x, p, V)
     # status 3 = non-finite coefficients: exactly the models for which the reference's formulas leave the reals
     # (gamma < 0 when rho(A - BK) + 0.4 > 1, utils.py:358-371)
@@ -110,7 +132,8 @@ def test_random_systems_dense_weights(solver, nx, nu, N, Bsz):
         assert rel(g[k][fin], h[k][fin]) < 1e-7, k
 
 
-def test_unstabilisable_model_is_reported(solver):
+def test_unstabilisable_model_is_reported(bsolver):
+    solver = bsolver
     A = np.zeros((2, 2, 70)); A[0, 0] = 1.5; A[1, 1] = 0.5
     B = np.zeros((2, 1, 70)); B[1, 0] = 1.0                        # the unstable mode is not reachable
     B[0, 0, 35:] = 1.0                                              # ... except in the second half of the batch
@@ -144,3 +167,31 @@ def test_slowly_damped_true_system_keeps_its_radius(solver):
     assert np.max(np.abs(beh.K_lqr - K)) <= 1e-9 * np.max(np.abs(K))
     pts = circle_generator(8, 1.5, eps, Q)
     assert pts.shape == (2, 8) and np.all(np.isfinite(pts))
+
+
+def test_c5_shape_on_chip_against_workspace_kernel_and_host(solver):
+    """n_x = 8, n_u = 4, N = 30 (C5: n = 120, one system per wavefront, 116 KB of LDS, compiled at run time): the on-chip kernels
+    against the HBM-workspace kernel on every output, and against the host oracle on a few systems."""
+    from lq_mpc_amd import synth, KERNEL_GENERIC, KERNEL_AUTO
+    b = synth.make_batch(5, Bsz=40)
+    N, Bsz = b["N"], 40
+    rng = np.random.default_rng(5)
+    eA, eB, MV = rng.uniform(1e-3, 1e-2, Bsz), rng.uniform(1e-3, 1e-2, Bsz), rng.uniform(0.1, 2.0, Bsz)
+    x, p, V = b["x0"][:, 0].copy(), P3, 1.3
+    a = (N, b["A"], b["B"], b["Q"], b["R"], b["lb"], b["ub"], eA, eB, MV, x, p, V)
+    try:
+        g = solver.bounds_batch(*a, want_aux=True)
+        assert solver.last_kernel() == CHIP
+        solver.set_options(kernel=KERNEL_GENERIC)
+        w = solver.bounds_batch(*a, want_aux=True)
+        assert solver.last_kernel() == WORKSPACE
+    finally:
+        solver.set_options(kernel=KERNEL_AUTO)
+    assert np.array_equal(g["status"], w["status"])
+    for k in ("eps", "rho_cl", "norm_A", "norm_B", "norm_K", "norm_Gamma", "norm_Phi", "min_eig_H", "alpha", "beta"):
+        assert rel(g[k], w[k]) < 1e-9, k
+    assert np.max(np.abs(g["K"] - w["K"])) < 1e-9 * np.abs(w["K"]).max()
+    idx = np.arange(0, Bsz, 13)
+    h = host_reference(N, b["A"][:, :, idx], b["B"][:, :, idx], b["Q"], b["R"], b["lb"], b["ub"], eA[idx], eB[idx], MV[idx], x, p, V)
+    for k in ("eps", "rho_cl", "norm_Gamma", "norm_Phi", "min_eig_H", "alpha", "beta"):
+        assert rel(g[k][idx], h[k]) < 1e-8, k
