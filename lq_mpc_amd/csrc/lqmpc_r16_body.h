@@ -216,6 +216,13 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     // a loop.  The row images ma, P_T ma, Q ma and the powers of A sit in LDS (the W region and the vectors
     // behind it, free until the inverse is stored).
     double G[RB][NX], vr[RB];
+    // P is read by the primal side of an iteration only (|A| > n / 2).  One instance per wavefront (LPI = 64, one wavefront in a
+    // hundred at C4): built in the set-up when the cold-start active set predicts a primal-side iteration at step 0, otherwise the
+    // first time an iteration needs it (C4 4.92 -> 4.58 ms).  Four instances per wavefront: in every set-up -- the mere presence of
+    // the on-demand call in qp() costs every primal-side iteration of these kernels ~25 % (C3 hard mix 1.27 -> 1.56 ms, default mix
+    // 0.338 -> 0.345 ms, measured with the call inside the iteration loop, outside it, and never taken).
+    constexpr bool LAZY_P = (LPI == 64);
+    bool P_ready = !LAZY_P;
 #ifdef LQMPC_R16_PROF
     const long long prof_t0 = clock64();
     int prof_wit = 0, prof_slow = 0, prof_fast = 0;
@@ -236,6 +243,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             Lg = (ldsd *)lds_raw + gq * C::INST;
         }
         r16_setup_mfma<NX, NU, N, LPI, PACKED, RB>(setup_args(p), bg, Lg, L, C::oW, C::oG, C::oD, G);
+        if constexpr (!LAZY_P) r16_build_P<NX, NU, N, LPI, PACKED>(setup_args(p), bg, Lg, C::oP, C::oD);
         RPROF(5);
         // constant part of the unconstrained minimiser: v_r = -W (2 gref + P centre) = -2 W gref - centre (references / off-centre boxes only)
         const bool has_lin = p.has_lin != 0;
@@ -306,6 +314,22 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 vr[s] = vrow[s] ? vr[s] - 0.5 * (sh[p.so.ub + k] + sh[p.so.lb + k]) : 0.0;
             }
         }
+        if constexpr (LAZY_P && MODE != MODE_MAXVN) {
+            // more than half of the rows of the unconstrained minimiser at x0 outside the box: the first iteration takes the primal side
+            mask_t out = 0;
+#pragma unroll
+            for (int s = 0; s < RB; ++s) {
+                double acc = vr[s];
+#pragma unroll
+                for (int a = 0; a < NX; ++a) acc = __builtin_fma(G[s][a], p.rec ? p.rec[b * REC + NX * NX + NX * NU + a] : p.x0[(long long)a * Bsz + b], acc);
+                const int k = rw[s] % NU;
+                out |= iballot<LPI>(vrow[s] && !(fabs(acc) <= 0.5 * (sh[p.so.ub + k] - sh[p.so.lb + k])), q) << (LPI * s);
+            }
+            if (__ballot(2 * __popcll(out) > n) != 0ull) {
+                r16_build_P<NX, NU, N, LPI, PACKED>(setup_args(p), bg, Lg, C::oP, C::oD);
+                P_ready = true;
+            }
+        }
         RPROF(6);
     }
     RPROF_START;
@@ -359,7 +383,6 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     const bool writer = valid && i == 0;
     mask_t pL = 0, pU = 0;                  // active set of the previous step (row-uniform bit masks)
     int iters = 0, status = 0;
-    bool P_ready = false;                   // P is built the first time an iteration of this wavefront takes the primal side (r16_build_P)
     // ---- one box QP at state x: v <- the optimum (my rows); updates the warm-start face, iters, status ----
     auto qp = [&](const double (&x)[NX], double (&v)[RB]) {
         double vu[RB];
@@ -389,9 +412,28 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             }
         }
         bool failed = false;
+        // The iterations.  Where P is built on demand (LAZY_P) the loop leaves with need_P, the call happens here, outside it, and the
+        // loop resumes at the same count.
+        int it = 0;
+        bool need_P = false;
+#pragma unroll 1
+        do {
+        if (LAZY_P && need_P) {
+            long long bg = bq;
+            ldsd *Lg = L;
+            if constexpr (LPI == 16) {
+                const int gq = (lane >> 2) & 3;
+                const long long sraw = slot0 + gq, sl = sraw < slot_end ? sraw : slot_end - 1;
+                bg = p.perm ? (long long)p.perm[sl] : sl;
+                Lg = (ldsd *)lds_raw + gq * C::INST;
+            }
+            r16_build_P<NX, NU, N, LPI, PACKED>(setup_args(p), bg, Lg, C::oP, C::oD);
+            P_ready = true;
+            need_P = false;
+        }
         if (__ballot(busy) != 0ull) {
 #pragma unroll 1
-            for (int it = 0; it < p.r16_maxit; ++it) {
+            for (; it < p.r16_maxit; ++it) {
 #ifdef LQMPC_R16_PROF
                 const long long prof_it0 = clock64();
 #endif
@@ -406,18 +448,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                              max(__builtin_amdgcn_readlane(c, 32), __builtin_amdgcn_readlane(c, 48)));
                 else cw = __builtin_amdgcn_readfirstlane(c);
                 const bool any_primal = __ballot(busy && !dual) != 0ull;
-                if (any_primal && !P_ready) {                    // wave-uniform
-                    long long bg = bq;
-                    ldsd *Lg = L;
-                    if constexpr (LPI == 16) {
-                        const int gq = (lane >> 2) & 3;
-                        const long long sraw = slot0 + gq, sl = sraw < slot_end ? sraw : slot_end - 1;
-                        bg = p.perm ? (long long)p.perm[sl] : sl;
-                        Lg = (ldsd *)lds_raw + gq * C::INST;
-                    }
-                    r16_build_P<NX, NU, N, LPI, PACKED>(setup_args(p), bg, Lg, C::oP, C::oD);
-                    P_ready = true;
-                }
+                if (LAZY_P && any_primal && !P_ready) { need_P = true; break; }     // wave-uniform: build P outside the loop, come back
                 if constexpr (LPI == 16) {
                     if (!any_primal) {
                         // ---- every busy instance of the wavefront is on the dual side: W_AA lam = r_A, v_F = v_unc,F - W_FA lam ----
@@ -904,6 +935,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 if (__ballot(busy) == 0ull) break;
             }
         }
+        } while (LAZY_P && need_P);
         if (busy) failed = true;
         if (failed || rowbad) {
             status = 3; pL = 0; pU = 0;
