@@ -432,7 +432,6 @@ def main():
         # (lqmpc_jit.hip; rounds 1-2 dropped such shapes onto the generic kernel, 650x slower)
         if args.config in (3, 4):
             Nj = N + 2
-            bj = synth.make_batch(args.config, Bsz=Bsz, fixture_dir=gold)
             try:
                 t0 = time.perf_counter()
                 s.rollout_batch_dev(nx, nu, Nj, Bsz, T, dA, dB, *shared, dx0, b["A_true"], b["B_true"], dJT, dstatus=dst, diters=dit)
@@ -450,7 +449,6 @@ def main():
                                                        "16-lane-row kernel; first_call_s includes the compile unless the code object was cached"}
             except Exception as e:
                 extra["untabled_shape"] = {"error": repr(e)}
-            del bj
         # closed-loop rollouts of small batches: us per MPC step (the reference runs ONE system per simulate(), utils_class.py:245-285)
         small = {}
         for m in (1, 64, 4096):
@@ -478,19 +476,22 @@ def main():
             sdg = BatchSolver(local_rank)
             beh = LQ_RDP_Behavior_Multiple(info_opc, info_N, info_e, 20, "f", data_dir=gold, solver=sdg)
             pdg = np.array([0.1, 1.0, 0.6])
-            beh.data_generation(8, 1.5, info_ref, pdg)
-            tw = []
+            beh.data_generation(8, 1.5, info_ref, pdg); beh.data_generation(8, 1.5, info_ref, pdg, concurrent=False)
+            tw, tseq = [], []
             for _ in range(5):
                 t0 = time.perf_counter(); og = beh.data_generation(8, 1.5, info_ref, pdg); tw.append(time.perf_counter() - t0)
+                t0 = time.perf_counter(); beh.data_generation(8, 1.5, info_ref, pdg, concurrent=False); tseq.append(time.perf_counter() - t0)
             ref_npz = np.load(os.path.join(gold, "data_lq_mpc_multipleSys.npz"))
             dev_ = float(np.max(np.abs(og["true_cost_error"] - ref_npz["true_cost_error"]) / np.abs(ref_npz["true_cost_error"])))
             sdg.close()
             extra["data_generation"] = {"wall_ms": round(min(tw) * 1e3, 3), "wall_ms_median": round(sorted(tw)[len(tw) // 2] * 1e3, 3),
+                                        "wall_ms_one_handle": round(min(tseq) * 1e3, 3),
                                         "qp_solves": 57001, "value": round(57001 / min(tw), 1), "unit": "QP-steps/s",
                                         "true_cost_error_max_rel_dev_vs_reference_npz": dev_,
                                         "workload": "lq_mpc_amd.sweep.LQ_RDP_Behavior_Multiple.data_generation on the reference's inputs "
                                                     "(error_{A,B}_f.npy, working_example_multiple.py constants): 1 500 systems x (8 open-loop "
-                                                    "+ 30 closed-loop QPs) + V_expert + the 13 npz arrays, host API, wall clock"}
+                                                    "+ 30 closed-loop QPs) + V_expert + the 13 npz arrays, host API, wall clock; wall_ms: the six passes (error levels, "
+                                                    "five horizons) on six handles / streams from a thread pool, wall_ms_one_handle: one after the other"}
         except Exception as e:                                          # (never at the price of the bench line)
             extra["data_generation"] = {"error": repr(e)}
         # single-call latency: the reference's call shape is ONE instance per solve() (utils_class.py:269)

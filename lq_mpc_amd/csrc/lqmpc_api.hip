@@ -598,13 +598,25 @@ int lqmpc_reserve(lqmpc_handle *h, int nx, int nu, int N, int64_t Bsz, int T)
     if (!h) return fail(LQMPC_ERR_BAD_ARG, "handle is NULL");
     int rc = check_dims(nx, nu, N, Bsz);
     if (rc) return rc;
-    (void)T;
+    if (T < 0) return fail(LQMPC_ERR_BAD_ARG, "T must be >= 0");
     HIP_TRY(hipSetDevice(h->device));
     rc = ensure(h, h->shared, 8192 * sizeof(double));
     if (rc) return rc;
-    if (!use_spec(h, nx, nu, N)) {
-        const size_t stride = (size_t)(Bsz + 63) / 64 * 64;
-        rc = ensure(h, h->ws, (size_t)lqmpc::generic_ws_entries(nx, nu, N) * stride * sizeof(double));
+    const bool fast = use_spec(h, nx, nu, N) || (h->opt.kernel == LQMPC_KERNEL_AUTO && h->opt.jit != 0 && lqmpc::jit_r16_shape(nx, nu, N, nullptr));
+    if (fast) {
+        // the hand-back list / order counters of the 16-lane-row kernels, and -- for rollouts long and large enough to be walked in
+        // difficulty order (T >= 4: lqmpc_rollout_batch_dev) -- the key, permutation and record buffers of the order
+        rc = ensure_fail(h, ((size_t)Bsz + FAIL_HDR) * sizeof(int));
+        if (!rc && T >= 4 && Bsz >= 1024) {
+            rc = ensure(h, h->key, (size_t)Bsz * sizeof(double));
+            if (!rc) rc = ensure(h, h->perm, (size_t)Bsz * sizeof(int));
+            if (!rc) rc = ensure(h, h->rec, (size_t)Bsz * (size_t)(nx * nx + nx * nu + nx) * sizeof(double));
+        }
+    }
+    if (!rc && !use_spec(h, nx, nu, N)) {
+        const bool wg_only = !fast && N * nu > 32;          // (the workgroup kernel needs no workspace)
+        const size_t cols = fast ? (size_t)JIT_FALLBACK_COLS : (size_t)(Bsz + 63) / 64 * 64;
+        if (!wg_only) rc = ensure(h, h->ws, (size_t)lqmpc::generic_ws_entries(nx, nu, N) * cols * sizeof(double));
     }
     return rc;
 }

@@ -91,16 +91,27 @@ class LQ_RDP_Behavior_Multiple:
             self._eps_lqr, self.K_lqr = float(r["eps"][0]), r["K"][:, :, 0].copy()
         return self._eps_lqr
 
-    def _bound_tables(self, N, A_stack, B_stack, e_level, M_V, x_start, V_expert, p):
-        """alpha, beta, xi, bound for a batch of models sharing horizon N (utils_class.py:837-859): one launch."""
-        r = self._s().bounds_batch(N, A_stack, B_stack, self.Q, self.R, self.lb, self.ub, e_level, e_level, M_V, x_start, p, V_expert)
+    @staticmethod
+    def _check_bounds_status(r):
         if np.any(r["status"] != 0):
             cnt = {int(k): int(np.sum(r["status"] == k)) for k in np.unique(r["status"]) if k != 0}
             raise RuntimeError(f"lqmpc_bounds_batch: models per non-zero status {cnt} (1 = dlqr doubling not settled, 2 = not "
                                "stabilisable, 3 = the bound formulas leave the reals: rho(A - BK) + 0.4 > 1, utils.py:358)")
-        return r["alpha"], r["beta"], r["xi"], r["bound"]
 
-    def data_generation(self, N_points, ext_radius_max, info_ref, p=None, save_path=None):
+    def _pool(self, k):
+        """k handles (own stream each) for the concurrent passes of data_generation: the reference's six passes (error levels, five
+        horizons) are independent, and each is latency-bound on its own (a few hundred instances)."""
+        if not hasattr(self, "_handles"):
+            self._handles = []
+        from .mpc import BatchSolver
+        while len(self._handles) < k:
+            self._handles.append(BatchSolver(self._s().device))
+        return self._handles[:k]
+
+    def data_generation(self, N_points, ext_radius_max, info_ref, p=None, save_path=None, concurrent=True):
+        """utils_class.py:766-959.  concurrent: the error-level pass and the five horizon passes (one fused sweep launch + one
+        bounds launch each) run on handles / streams of their own from a thread pool (ctypes releases the GIL); False: one after
+        the other on the solver's own handle."""
         s = self._s()
         nx, nu = self.B_true.shape
         Q, R, lb, ub = self.Q, self.R, self.lb, self.ub
@@ -114,38 +125,45 @@ class LQ_RDP_Behavior_Multiple:
         B = np.ascontiguousarray((self.B_true[:, :, None, None] + self.error_B).reshape(nx, nu, -1))
         Bsz = A.shape[2]
         x0 = np.repeat(x_start[:, None], Bsz, axis=1)
-        N = self.N_nominal
-        # M_V (8 open-loop solves per system) and the closed-loop cost share one launch: lqmpc_sweep_batch
-        res = s.sweep_batch(self.N_mpc, N, A, B, Q, R, Q, lb, ub, x0, x0_vec, self.A_true, self.B_true,
-                            info_ref.get("x_ref"), info_ref.get("u_ref"))
-        M_V_error, J = res["M_V"], res["J_T"]
-        true_cost_error = J.reshape(self.N_sys, n_err)
-        M_V_error = M_V_error.reshape(self.N_sys, n_err)
         # horizon sweep on error column index_sys = 4 (utils_class.py:880-883), zero references (887-888)
         A4 = np.ascontiguousarray(self.A_true[:, :, None] + self.error_A[:, :, :, 4])
         B4 = np.ascontiguousarray(self.B_true[:, :, None] + self.error_B[:, :, :, 4])
         x04 = np.repeat(x_start[:, None], self.N_sys, axis=1)
-        true_cost_horizon = np.zeros((self.N_sys, len(self.horizon)))
-        M_V_horizon = np.zeros((self.N_sys, len(self.horizon)))
-        for i, Nh in enumerate(self.horizon):
-            Nh = int(Nh)
-            res = s.sweep_batch(self.N_mpc, Nh, A4, B4, Q, R, Q, lb, ub, x04, x0_vec, self.A_true, self.B_true)
-            M_V_horizon[:, i], true_cost_horizon[:, i] = res["M_V"], res["J_T"]
+        lev = np.tile(self.error_vec, self.N_sys)             # the error level of instance (j, i) is error_vec[i]
+        lev4 = np.full(self.N_sys, self.e_nominal)
+
+        def one_pass(sv, N, Am, Bm, x0m, xr, ur, levels):
+            """M_V (8 open-loop solves per system) and the closed-loop cost in one launch (lqmpc_sweep_batch), then the bound
+            coefficients of the same models (lqmpc_bounds_batch)"""
+            res = sv.sweep_batch(self.N_mpc, N, Am, Bm, Q, R, Q, lb, ub, x0m, x0_vec, self.A_true, self.B_true, xr, ur)
+            co = None
+            if p is not None:
+                r = sv.bounds_batch(N, Am, Bm, Q, R, lb, ub, levels, levels, res["M_V"], x_start, p, V_expert)
+                self._check_bounds_status(r)
+                co = (r["alpha"], r["beta"], r["xi"], r["bound"])
+            return res["M_V"], res["J_T"], co
+        jobs = [(self.N_nominal, A, B, x0, info_ref.get("x_ref"), info_ref.get("u_ref"), lev)]
+        jobs += [(int(Nh), A4, B4, x04, None, None, lev4) for Nh in self.horizon]
+        if concurrent:
+            from concurrent.futures import ThreadPoolExecutor
+            handles = self._pool(len(jobs))
+            if not hasattr(self, "_executor"):
+                self._executor = ThreadPoolExecutor(max_workers=len(jobs))
+            results = list(self._executor.map(lambda hj: one_pass(hj[0], *hj[1]), zip(handles, jobs)))
+        else:
+            results = [one_pass(s, *j) for j in jobs]
+        M_V_error, J, co_err = results[0]
+        true_cost_error = J.reshape(self.N_sys, n_err)
+        M_V_error = M_V_error.reshape(self.N_sys, n_err)
+        true_cost_horizon = np.stack([r[1] for r in results[1:]], axis=1)
+        M_V_horizon = np.stack([r[0] for r in results[1:]], axis=1)
         out = {"error": self.error_vec, "horizon": self.horizon, "V_expert": V_expert,
                "true_cost_error": true_cost_error, "true_cost_horizon": true_cost_horizon}
         if p is not None:
-            # the scalar bound coefficients (host side); the error level of instance (j, i) is error_vec[i]
-            lev = np.tile(self.error_vec, self.N_sys)
-            al, be, xi, bd = self._bound_tables(N, A, B, lev, M_V_error.reshape(-1), x_start, V_expert, p)
-            for k, v in (("alpha", al), ("beta", be), ("xi", xi), ("bound", bd)):
+            for k, v in zip(("alpha", "beta", "xi", "bound"), co_err):
                 out[f"{k}_table_error"] = v.reshape(self.N_sys, n_err)
-            for k in ("alpha", "beta", "xi", "bound"):
-                out[f"{k}_table_horizon"] = np.zeros((self.N_sys, len(self.horizon)))
-            lev4 = np.full(self.N_sys, self.e_nominal)
-            for i, Nh in enumerate(self.horizon):
-                al, be, xi, bd = self._bound_tables(int(Nh), A4, B4, lev4, M_V_horizon[:, i], x_start, V_expert, p)
-                out["alpha_table_horizon"][:, i], out["beta_table_horizon"][:, i] = al, be
-                out["xi_table_horizon"][:, i], out["bound_table_horizon"][:, i] = xi, bd
+            for j, k in enumerate(("alpha", "beta", "xi", "bound")):
+                out[f"{k}_table_horizon"] = np.stack([r[2][j] for r in results[1:]], axis=1)
             if save_path is not None:
                 np.savez(save_path, **out)                                             # utils_class.py:958
         out.update({"M_V_error": M_V_error, "M_V_horizon": M_V_horizon, "x0_vec": x0_vec})
