@@ -541,7 +541,7 @@ __device__ __forceinline__ void bounds_big(const BoundsParams &p, double *lds_ra
                 }
             }
             __syncthreads();
-            // the product is symmetric when Q is; mirror the lower triangle as the host oracle does
+            // the product is symmetric when Q is; mirror the lower triangle (as the workspace kernel does)
 #pragma unroll
             for (int s = 0; s < RB; ++s) {
                 const int row = i + LPI * s;
