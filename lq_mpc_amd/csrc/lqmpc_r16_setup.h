@@ -303,27 +303,29 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
     const double Rp = (r == c && r >= NU && r < NUP) ? 1.0 : ld.S(p.oR, r, c, NU);   // (a dummy input weighs 1)
 
     // ---- backward sweep: Riccati recursion, the rows rho_k, W by one update per column tile ----
-    double Wacc[NTM][NT];                         // tile (I, J), J <= I: LPI = 16: Wacc[I][J]; LPI = 64: block g of Wacc[m][J] holds tile (4m+g, J)
+    // LPI = 16: W by 4 x 4 tiles, Wacc[I][J], J <= I.  LPI = 64 (tile I in block I % 4 of register I / 4): the four tiles of a
+    // register are, lane for lane, the A / B operand of v_mfma_f64_16x16x4_f64 for rows 16m .. 16m+15 (lane 16x + 4g + y holds
+    // [column x of the column tile][row 4g + y]) -- so W is accumulated by 16 x 16 blocks, Wb[m(m+1)/2 + m'], one instruction per
+    // block and column tile, and no operand has to be replicated over the blocks.
+    double Wacc[(LPI == 16) ? NTM : 1][(LPI == 16) ? NT : 1];
+    wg::d4_t Wb[(LPI == 64) ? NTM * (NTM + 1) / 2 : 1];
     double rho[NTM][TX];                          // rho' of the rows of tile I (n_x x 4: column = row of the tile), by row tiles
-    double rho_r[(LPI == 64) ? NT : 1][TX];       // LPI = 64: every tile's rho' in every block (the B operand of an update is one tile for all)
     // T(:, M)' and (T(:, M) D_M^-1 / 2)' of the current column tile M on the rows of every tile from M on: register-matrix row
     // q NUP + u <-> column u of stage M SPT + q; filled stage by stage (the accumulator operand), used once per column tile
-    double TtA[NT], TDA[NTM];
+    double TtA[NTM], TDA[NTM];
 #pragma unroll
     for (int m = 0; m < NTM; ++m) {
-        TDA[m] = 0.0;
+        TDA[m] = 0.0; TtA[m] = 0.0;
 #pragma unroll
         for (int a = 0; a < TX; ++a) rho[m][a] = 0.0;
+        if constexpr (LPI == 16) {
 #pragma unroll
-        for (int J = 0; J < NT; ++J) Wacc[m][J] = 0.0;
+            for (int J = 0; J < NT; ++J) Wacc[m][J] = 0.0;
+        }
     }
-#pragma unroll
-    for (int J = 0; J < NT; ++J) TtA[J] = 0.0;
     if constexpr (LPI == 64) {
 #pragma unroll
-        for (int J = 0; J < NT; ++J)
-#pragma unroll
-            for (int a = 0; a < TX; ++a) rho_r[J][a] = 0.0;
+        for (int e = 0; e < NTM * (NTM + 1) / 2; ++e) Wb[e] = wg::d4_t{0.0, 0.0, 0.0, 0.0};
     }
     // o' = Acl' o (+ add) on an n_x x 4 column of tiles
     auto advance = [&](double (&o)[TX], const double (&Acl)[TX][TX], const double (&add)[TX], bool with_add) {
@@ -439,23 +441,18 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
             });
         } else {
             constexpr int m0 = Ij / 4;
-            sfor<Ij, NT>([&](auto Jc) {
-                constexpr int J = decltype(Jc)::value;
-                const double cT = (first_of_tile ? 0.0 : TtA[J]) + (J == Ij ? Iq : 0.0);
-                if constexpr (T::live(J, j)) TtA[J] = dotc(nBpl[q], rho_r[J], cT);
-                else TtA[J] = cT;
-            });
             sfor<m0, NTM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 const bool mine = (4 * m + g == Ij);
+                TtA[m] = dotc(nBpl[q], rho[m], (first_of_tile ? 0.0 : TtA[m]) + (mine ? Iq : 0.0));
                 TDA[m] = dotc(nBRt, rho[m], (first_of_tile ? 0.0 : TDA[m]) + (mine ? Rqq : 0.0));
             });
             if constexpr (q == 0) {
-                sfor<Ij, NT>([&](auto Jc) {
-                    constexpr int J = decltype(Jc)::value;
-                    sfor<J / 4, NTM>([&](auto mc) {
-                        constexpr int m = decltype(mc)::value;
-                        Wacc[m][J] = mm4(TDA[m], TtA[J], Wacc[m][J]);     // (blocks whose tile 4m+g < J compute an upper-triangle tile: never stored)
+                sfor<m0, NTM>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    sfor<m0, m + 1>([&](auto nc) {
+                        constexpr int m2 = decltype(nc)::value;
+                        Wb[m * (m + 1) / 2 + m2] = __builtin_amdgcn_mfma_f64_16x16x4f64(TDA[m], TtA[m2], Wb[m * (m + 1) / 2 + m2], 0, 0, 0);
                     });
                 });
             }
@@ -466,14 +463,6 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
 #pragma unroll
                 for (int a = 0; a < TX; ++a) add[a] = mine ? Ktp[a] : 0.0;
                 advance(rho[m], Acl, add, true);
-            });
-            sfor<Ij, NT>([&](auto Jc) {
-                constexpr int J = decltype(Jc)::value;
-                if constexpr (T::live(J, j)) advance(rho_r[J], Acl, Ktp, J == Ij);
-                else {
-#pragma unroll
-                    for (int a = 0; a < TX; ++a) rho_r[J][a] = Ktp[a];
-                }
             });
         }
     });
@@ -503,13 +492,30 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
     __syncthreads();
 
     // ---- W to LDS ----
+    if constexpr (LPI == 16) {
 #pragma unroll
-    for (int m = 0; m < NTM; ++m)
+        for (int I = 0; I < NT; ++I)
 #pragma unroll
-        for (int J = 0; J < NT; ++J) {
-            const int I = (LPI == 16) ? m : 4 * m + g;
-            if ((LPI == 16) ? (J <= m) : (J <= 4 * m + 3)) store_tile<T, PACKED>(Wp, dW, I, J, Wacc[m][J], I < NT && J <= I, r, c);
-        }
+            for (int J = 0; J <= I; ++J) store_tile<T, PACKED>(Wp, dW, I, J, Wacc[I][J], true, r, c);
+    } else {
+        // a 16 x 16 block of the tiled row space: lane l, register e holds entry (16m + l / 16 + 4e, 16m' + l % 16)
+        constexpr int LDW = n + 1;
+#pragma unroll
+        for (int m = 0; m < NTM; ++m)
+#pragma unroll
+            for (int m2 = 0; m2 <= m; ++m2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = T::row_of(16 * m + (lane >> 4) + 4 * e), col = T::row_of(16 * m2 + (lane & 15));
+                    const bool low = row >= 0 && col >= 0 && col <= row;
+                    const double val = Wb[m * (m + 1) / 2 + m2][e];
+                    if constexpr (PACKED) Wp[low ? row * (row + 1) / 2 + col : dW] = val;
+                    else {
+                        Wp[low ? row * LDW + col : dW] = val;
+                        Wp[(low && col < row) ? col * LDW + row : dW] = val;
+                    }
+                }
+    }
     __syncthreads();
 }
 
