@@ -45,14 +45,14 @@ bool jit_r16_shape(int nx, int nu, int N, int *lpi)
 // R16<NX, NU, N, LPI, PACKED>::INST restated for run-time dimensions (doubles of LDS per instance)
 static int r16_inst(int nx, int nu, int N, int lpi, bool packed)
 {
-    const int n = N * nu, rb = (n + lpi - 1) / lpi, cs = lpi == 16 ? 16 : 24, ldw = n + 1;
+    const int n = N * nu, rb = (n + lpi - 1) / lpi, cs = 4 * (((n + 1) / 2 + 3) / 4), ldw = n + 1;
     const int pk = packed ? n * (n + 1) / 2 : n * ldw, vec = lpi * rb;
     const int cn0 = 3 * nx * nx + nu * nu + nx * nu, cn1 = (nx > nu ? nx : nu) * (2 * nx + 2 * nu), cn = cn0 > cn1 ? cn0 : cn1;
     const int oR = 2 * pk, oL = oR + 3 * vec, oC = oL + cs / 2;
     const int setup = n * nx, end = oC + cn + (cn & 1), oD = end > setup ? end : setup;
     return oD + 2;
 }
-static_assert(R16<4, 2, 10, 16, true>::INST == 586 && R16<2, 1, 30, 16, true>::INST == 1052 && R16<4, 2, 20, 64, true>::INST == 1906,
+static_assert(R16<4, 2, 10, 16, true>::INST == 584 && R16<2, 1, 30, 16, true>::INST == 1052 && R16<4, 2, 20, 64, true>::INST == 1904,
               "r16_inst() below restates this arithmetic: keep the two in step");
 
 struct Build { int lpi, occ, waves, inst; };

@@ -44,7 +44,7 @@ struct R16 {
     static constexpr int n = N * NU;
     static constexpr int RB = (n + LPI - 1) / LPI;
     static constexpr int IPW = 64 / LPI;              // instances per wavefront
-    static constexpr int CS = (LPI == 16) ? 16 : 24;  // most unknowns of a gathered system: min(|A|, |F|) <= n / 2
+    static constexpr int CS = 4 * (((n + 1) / 2 + 3) / 4);   // most unknowns of a gathered system: min(|A|, |F|) <= n / 2, in groups of four
     static constexpr int LDW = n + 1;                // row stride of P and W: odd, so that a column read is conflict-free
     // P and W: full rows (every access is row base + constant) or, for the builds that need the LDS for a second wave per
     // SIMD, the packed lower triangle (an address select per access)
@@ -223,6 +223,15 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
     // 0.338 -> 0.345 ms, measured with the call inside the iteration loop, outside it, and never taken).
     constexpr bool LAZY_P = (LPI == 64);
     bool P_ready = !LAZY_P;
+    // the set-up's guess of the active set at x0 (lqmpc_r16_setup.h, ROLL): the face the first, cold-started QP begins from; the
+    // stage gains are kept in registers through the sweep, so short horizons only, and where the first QP is the one at x0
+#ifdef LQMPC_NO_ROLL                         // (dev builds: tools/prof_build.sh)
+    constexpr bool ROLL = false;
+#else
+    constexpr bool ROLL = LPI == 16 && N * ((NX + 3) / 4) <= 12 && MODE != MODE_MAXVN;
+#endif
+    unsigned cold32[2] = {0u, 0u};
+    bool cold_armed = false;                 // set by the caller of qp() for the QP at x0
 #ifdef LQMPC_R16_PROF
     const long long prof_t0 = clock64();
     int prof_wit = 0, prof_slow = 0, prof_fast = 0;
@@ -242,7 +251,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             bg = p.perm ? (long long)p.perm[sl] : sl;
             Lg = (ldsd *)lds_raw + gq * C::INST;
         }
-        r16_setup_mfma<NX, NU, N, LPI, PACKED, RB>(setup_args(p), bg, Lg, L, C::oW, C::oG, C::oD, G);
+        r16_setup_mfma<NX, NU, N, LPI, PACKED, RB, ROLL>(setup_args(p), bg, Lg, L, C::oW, C::oG, C::oD, G, roll_args(p), cold32[0], cold32[1]);
         if constexpr (!LAZY_P) r16_build_P<NX, NU, N, LPI, PACKED>(setup_args(p), bg, Lg, C::oP, C::oD);
         RPROF(5);
         // constant part of the unconstrained minimiser: v_r = -W (2 gref + P centre) = -2 W gref - centre (references / off-centre boxes only)
@@ -407,10 +416,13 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 const mask_t top = nmask & ~(nmask >> NU);
                 mL = (pL >> NU) | (pL & top);
                 mU = (pU >> NU) | (pU & top);
+            } else if (ROLL && cold_armed && (cold32[0] | cold32[1]) != 0u) {
+                mL = cold32[0]; mU = cold32[1];
             } else {
                 mL = cl; mU = cu;
             }
         }
+        cold_armed = false;
         bool failed = false;
         // The iterations.  Where P is built on demand (LAZY_P) the loop leaves with need_P, the call happens here, outside it, and the
         // loop resumes at the same count.
@@ -1036,6 +1048,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             double x[NX], v[RB], u[NU];
 #pragma unroll
             for (int a = 0; a < NX; ++a) x[a] = p.rec ? p.rec[bq * REC + NX * NX + NX * NU + a] : p.x0[(long long)a * Bsz + bq];
+            cold_armed = ROLL;
             qp(x, v);
             const double vn = value_fn(x, v);
             stage_input(v, 0, u);
@@ -1139,6 +1152,7 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
                 }
                 inside = __ballot(out) == 0ull;
             }
+            cold_armed = ROLL && t == 0;
             if (inside) { pL = 0; pU = 0; }
             else qp(x, v);
             const double um = fmin(fmax(v[0], -h[0]), h[0]) + ctr[0];     // the input of my first row: u_i in lane i < NU

@@ -103,6 +103,13 @@ struct SetupArgs {
     int oQ, oP, oR;
 };
 __device__ __forceinline__ SetupArgs setup_args(const KParams &p) { return SetupArgs{p.rec, p.A, p.B, p.sh, p.Bsz, p.so.Q, p.so.P, p.so.R}; }
+// ... and of the cold-start guess (r16_setup_mfma<.., ROLL = true>): the first state, the box, whether the guess applies at all.
+// (Kept out of SetupArgs: past 64 bytes the by-value argument of r16_build_P goes through scratch.)
+struct RollArgs {
+    const double *x0;
+    int oLb, oUb, roll;
+};
+__device__ __forceinline__ RollArgs roll_args(const KParams &p) { return RollArgs{p.x0, p.so.lb, p.so.ub, p.has_lin == 0}; }
 
 // Zero-padded loads of one instance's model (instance-minor arrays or the probe's instance-major records) and of the shared weights
 template <int NX, int NU>
@@ -275,10 +282,22 @@ __device__ __attribute__((noinline)) void r16_build_P(const SetupArgs p, long lo
 // P / W: they are written after G has been read back); oD: a dummy slot for predicated stores.
 // bg: the instance block g works on.  Lq: where the lane's OWN instance (q = lane / LPI) reads its rows of G back.
 // On return: W in LDS (a barrier has been passed), G[s][a] = row (i + LPI s) of G in registers.  P: r16_build_P, on demand.
-template <int NX, int NU, int N, int LPI, bool PACKED, int RB>
+//
+// ROLL (four instances per wavefront, short horizons): a first guess of the active set at the first state x0, for the cold start of
+// the primal-dual active-set iteration.  The model is rolled forward under the gains of the sweep with the inputs clipped to the box,
+//     u_j = clip(-K_j x_j),  x_{j+1} = A x_j + B u_j,   guess = the (stage, input) pairs that clipped, by side
+// -- i.e. forward substitution through T with clipping.  It predicts the optimal face far better than "the rows of the unconstrained
+// minimiser outside the box": primal-dual iterations at step 0 of C3's default mix 2.19 -> 1.40 per QP, hard mix 4.40 -> 2.51
+// (tools/proto/cold_start_guess.py, warm_start_guess.py; later steps keep the shifted face of the previous step, which is better
+// still).  On the matrix core like the rest: K_j' is kept per stage (N TX register matrices), a stage is three dependent products
+// and a clip for the four instances at once.  Zero references and a centred box only: otherwise -K_j x_j is not the
+// unconstrained input (ra.roll).  coldL / coldU: bit (j NU + k) per clipped pair, in the lanes of the instance (q = lane / 16) as everywhere
+// outside the set-up; both zero: no guess.
+template <int NX, int NU, int N, int LPI, bool PACKED, int RB, bool ROLL = false>
 __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg, wg::ldsd *Lg, wg::ldsd *Lq, int oW, int oG, int oD,
-                                              double (&G)[RB][NX])
+                                              double (&G)[RB][NX], const RollArgs &ra, unsigned &coldL, unsigned &coldU)
 {
+    static_assert(!ROLL || (LPI == 16 && N * NU <= 32), "the cold-start roll serves the four-instance mapping");
     using T = SetupT<NX, NU, N, LPI>;
     constexpr int n = T::n, NT = T::NT, SPT = T::SPT, NTM = T::NTM, TX = T::TX, NUP = T::NUP;
     const int lane = threadIdx.x, r = lane >> 4, c = lane & 3, g = (lane >> 2) & 3;
@@ -313,6 +332,7 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
     // T(:, M)' and (T(:, M) D_M^-1 / 2)' of the current column tile M on the rows of every tile from M on: register-matrix row
     // q NUP + u <-> column u of stage M SPT + q; filled stage by stage (the accumulator operand), used once per column tile
     double TtA[NTM], TDA[NTM];
+    double KT[ROLL ? N : 1][TX];                  // K_j' (n_x x 4, by row tiles) of every stage, for the roll after the sweep
 #pragma unroll
     for (int m = 0; m < NTM; ++m) {
         TDA[m] = 0.0; TtA[m] = 0.0;
@@ -379,6 +399,10 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
         const double R0 = small_inverse<NUP>(Re, r, c);
 #pragma unroll
         for (int b = 0; b < TX; ++b) K[b] = mm4(R0, F[b]);
+        if constexpr (ROLL) {
+#pragma unroll
+            for (int b = 0; b < TX; ++b) KT[j][b] = mm4(F[b], R0);
+        }
 #pragma unroll
         for (int a = 0; a < TX; ++a)
 #pragma unroll
@@ -490,6 +514,66 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
         }
     }
     __syncthreads();
+
+    // ---- the cold-start guess: saturated roll-forward from x0 (column 0 of a register matrix per row tile) ----
+    // (here, in one block with the stores of W: its dependent chain of products runs under their address arithmetic and LDS issue)
+    coldL = 0u; coldU = 0u;
+    if constexpr (ROLL) {
+        unsigned bL = 0u, bU = 0u;                                    // lane (r = k, c = 0) of block g: the flags of input k of instance g
+        if (ra.roll) {
+            constexpr int REC = NX * NX + NX * NU + NX;
+            const double I4 = (r == c) ? 1.0 : 0.0;
+            double At[TX][TX], xr[TX];
+#pragma unroll
+            for (int a = 0; a < TX; ++a) {
+#pragma unroll
+                for (int b = 0; b < TX; ++b) At[b][a] = mm4(A[a][b], I4);          // (A tile)': mm4(At[b][a], x_b) = A_ab x_b
+                const bool v = c == 0 && 4 * a + r < NX;
+                const int ia = v ? 4 * a + r : 0;
+                const double x = p.rec ? p.rec[bg * REC + NX * NX + NX * NU + ia] : ra.x0[(long long)ia * p.Bsz + bg];
+                xr[a] = v ? x : 0.0;
+            }
+            const int kk = r < NU ? r : 0;
+            const double hk = (r < NU) ? 0.5 * (p.sh[ra.oUb + kk] - p.sh[ra.oLb + kk]) : 1.0;
+            const unsigned one = (c == 0 && r < NU) ? (1u << r) : 0u;
+            sfor<0, N>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                double kx = 0.0;                                          // K_j x_j = -u_j before the clip
+#pragma unroll
+                for (int b = 0; b < TX; ++b) kx = mm4(KT[j][b], xr[b], kx);
+                double xn[TX];                                            // A x_j first: it does not wait for the clip
+                if constexpr (j + 1 < N) {
+#pragma unroll
+                    for (int a = 0; a < TX; ++a) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int b = 0; b < TX; ++b) v = mm4(At[b][a], xr[b], v);
+                        xn[a] = v;
+                    }
+                }
+                bL |= (kx > hk) ? (one << (j * NU)) : 0u;                 // u_j < -h: lower bound
+                bU |= (kx < -hk) ? (one << (j * NU)) : 0u;
+                const double un = fmin(fmax(kx, -hk), hk);
+                if constexpr (j + 1 < N) {
+#pragma unroll
+                    for (int a = 0; a < TX; ++a) xr[a] = mm4(nBt[a], un, xn[a]);   // + (-B)(-u_j)
+                }
+            });
+        }
+        // the flags of instance gq sit in lanes 16 k + 4 gq (k < NU): gather them, hand each instance its own
+        unsigned mLq[4], mUq[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            mLq[gq] = 0u; mUq[gq] = 0u;
+#pragma unroll
+            for (int k = 0; k < NU; ++k) {
+                mLq[gq] |= (unsigned)__builtin_amdgcn_readlane((int)bL, 16 * k + 4 * gq);
+                mUq[gq] |= (unsigned)__builtin_amdgcn_readlane((int)bU, 16 * k + 4 * gq);
+            }
+        }
+        coldL = r == 0 ? mLq[0] : (r == 1 ? mLq[1] : (r == 2 ? mLq[2] : mLq[3]));     // (r = lane >> 4 = the instance of the lane)
+        coldU = r == 0 ? mUq[0] : (r == 1 ? mUq[1] : (r == 2 ? mUq[2] : mUq[3]));
+    }
 
     // ---- W to LDS ----
     if constexpr (LPI == 16) {
