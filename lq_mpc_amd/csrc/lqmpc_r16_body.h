@@ -1092,11 +1092,14 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             Br_[k] = p.true_per_instance ? p.Bt[(long long)(ia * NU + k) * Bsz + bq] : sh[p.so.Bt + ia * NU + k];
             Rr_[k] = sh[p.so.R + ik * NU + k];
         }
-        // built for two waves per SIMD: my rows live in the LDS constants region (the open-loop part is done with it), read per step
+        // one instance per wavefront, built for two waves per SIMD: my rows live in the LDS constants region (the open-loop part is done
+        // with it), read per step.  Four instances per wavefront keep them in registers (24 at C3: the free steps of a rollout read
+        // nothing from LDS; C3 0.325 -> 0.318 ms)
+        constexpr bool ROWS_IN_LDS = OCC == 2 && LPI == 64;
         constexpr int RW = 2 * NX + 2 * NU;
         static_assert((NX > NU ? NX : NU) * RW <= C::CN + (C::CN & 1), "the per-lane rows fit the constants region");
         ldsd *myc = L + C::oC + ((i < NX || i < NU) ? i : 0) * RW;
-        if constexpr (OCC == 2) {
+        if constexpr (ROWS_IN_LDS) {
             __syncthreads();
             if (i < NX || i < NU) {
 #pragma unroll
@@ -1106,10 +1109,10 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             }
             __syncthreads();
         }
-        auto Ar = [&](int c) -> double { if constexpr (OCC == 2) return myc[c]; else return Ar_[c]; };
-        auto Br = [&](int k) -> double { if constexpr (OCC == 2) return myc[NX + k]; else return Br_[k]; };
-        auto Qr = [&](int c) -> double { if constexpr (OCC == 2) return myc[NX + NU + c]; else return Qr_[c]; };
-        auto Rr = [&](int k) -> double { if constexpr (OCC == 2) return myc[2 * NX + NU + k]; else return Rr_[k]; };
+        auto Ar = [&](int c) -> double { if constexpr (ROWS_IN_LDS) return myc[c]; else return Ar_[c]; };
+        auto Br = [&](int k) -> double { if constexpr (ROWS_IN_LDS) return myc[NX + k]; else return Br_[k]; };
+        auto Qr = [&](int c) -> double { if constexpr (ROWS_IN_LDS) return myc[NX + NU + c]; else return Qr_[c]; };
+        auto Rr = [&](int k) -> double { if constexpr (ROWS_IN_LDS) return myc[2 * NX + NU + k]; else return Rr_[k]; };
         double costx, costu = 0.0;
         {
             double xm = x[0], qx = 0.0;
