@@ -451,7 +451,12 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
 #endif
                 const mask_t mA = mL | mU;
                 const int m = __popcll(mA);
-                const bool dual = 2 * m <= n;                     // row-uniform: the smaller side
+                // row-uniform: the smaller side -- with a bias to the dual side where the wavefront holds four instances: one of them on
+                // the primal side takes all four through the general path (twice the price of a dual-only iteration), so a face of up
+                // to n/2 + 2 rows is still solved from the dual side (C3 rollout 0.327 -> 0.323 ms, hard mix 1.215 -> 1.195 ms;
+                // at n = 10 the larger gathered system costs more than it saves)
+                constexpr int DUAL_MAX = (LPI == 16 && n >= 16) ? (n / 2 + 2 < CS ? n / 2 + 2 : CS) : n / 2;
+                const bool dual = m <= DUAL_MAX;
                 const mask_t mC = busy ? (dual ? mA : (~mA & nmask)) : 0ull;
                 const int c = __popcll(mC);
                 int cw;                                          // wave maximum: uniform loop bound (c is row-uniform: one lane per row)
