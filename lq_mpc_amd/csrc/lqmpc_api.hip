@@ -336,6 +336,49 @@ static bool host_sym_eig_extremes(const double *Min, int n, double &emax, double
     return std::isfinite(emax) && std::isfinite(emin);
 }
 
+// First gain K_0 of the N-stage problem on (A, B): S_N = P, K_j = (R + B'S B)^-1 B'S A, S <- Q + A'S (A - B K_j).  Row-major, nu x nx.
+// (Host, once per call of a rollout with a shared plant: the difficulty order's roll uses it; 10 x O(nx^3) flops.)
+static bool host_first_gain(int nx, int nu, int N, const double *A, const double *B, const double *Q, const double *R, const double *P, double *K)
+{
+    std::vector<double> S(P, P + nx * nx), SA(nx * nx), SB(nx * nu), Re(nu * nu), F(nu * nx), Acl(nx * nx), T(nx * nx);
+    for (int j = 0; j < N; ++j) {
+        for (int a = 0; a < nx; ++a) {
+            for (int c = 0; c < nx; ++c) { double t = 0.0; for (int k = 0; k < nx; ++k) t += S[a * nx + k] * A[k * nx + c]; SA[a * nx + c] = t; }
+            for (int c = 0; c < nu; ++c) { double t = 0.0; for (int k = 0; k < nx; ++k) t += S[a * nx + k] * B[k * nu + c]; SB[a * nu + c] = t; }
+        }
+        for (int r = 0; r < nu; ++r) {
+            for (int c = 0; c < nu; ++c) { double t = R[r * nu + c]; for (int k = 0; k < nx; ++k) t += B[k * nu + r] * SB[k * nu + c]; Re[r * nu + c] = t; }
+            for (int c = 0; c < nx; ++c) { double t = 0.0; for (int k = 0; k < nx; ++k) t += B[k * nu + r] * SA[k * nx + c]; F[r * nx + c] = t; }
+        }
+        // K = Re^-1 F by Gaussian elimination with partial pivoting (nu <= 8)
+        for (int col = 0; col < nu; ++col) {
+            int piv = col;
+            for (int r = col + 1; r < nu; ++r) if (std::fabs(Re[r * nu + col]) > std::fabs(Re[piv * nu + col])) piv = r;
+            if (!(std::fabs(Re[piv * nu + col]) > 0.0)) return false;
+            if (piv != col) {
+                for (int c = 0; c < nu; ++c) std::swap(Re[piv * nu + c], Re[col * nu + c]);
+                for (int c = 0; c < nx; ++c) std::swap(F[piv * nx + c], F[col * nx + c]);
+            }
+            const double inv = 1.0 / Re[col * nu + col];
+            for (int r = 0; r < nu; ++r) {
+                if (r == col) continue;
+                const double f = Re[r * nu + col] * inv;
+                for (int c = 0; c < nu; ++c) Re[r * nu + c] -= f * Re[col * nu + c];
+                for (int c = 0; c < nx; ++c) F[r * nx + c] -= f * F[col * nx + c];
+            }
+        }
+        for (int r = 0; r < nu; ++r) { const double inv = 1.0 / Re[r * nu + r]; for (int c = 0; c < nx; ++c) K[r * nx + c] = F[r * nx + c] * inv; }
+        for (int a = 0; a < nx; ++a)
+            for (int c = 0; c < nx; ++c) { double t = A[a * nx + c]; for (int k = 0; k < nu; ++k) t -= B[a * nu + k] * K[k * nx + c]; Acl[a * nx + c] = t; }
+        for (int a = 0; a < nx; ++a)
+            for (int c = 0; c < nx; ++c) { double t = 0.0; for (int k = 0; k < nx; ++k) t += S[a * nx + k] * Acl[k * nx + c]; T[a * nx + c] = t; }
+        for (int a = 0; a < nx; ++a)
+            for (int c = 0; c < nx; ++c) { double t = Q[a * nx + c]; for (int k = 0; k < nx; ++k) t += A[k * nx + a] * T[k * nx + c]; S[a * nx + c] = t; }
+    }
+    for (int e = 0; e < nu * nx; ++e) if (!std::isfinite(K[e])) return false;
+    return true;
+}
+
 static bool use_spec(const lqmpc_handle *h, int nx, int nu, int N)
 {
     return h->opt.kernel != LQMPC_KERNEL_GENERIC && h->opt.kernel != LQMPC_KERNEL_WORKGROUP && lqmpc::spec_available(nx, nu, N);
@@ -378,6 +421,15 @@ static int prepare(lqmpc_handle *h, const Call &c, KParams &p)
     p.so.At = put(c.true_per_instance ? nullptr : c.At_sh, nx * nx);
     p.so.Bt = put(c.true_per_instance ? nullptr : c.Bt_sh, nx * nu);
     p.so.x0s = put(c.x0s, c.x0s ? nx * c.K : 1);
+    // the difficulty order's key for rollouts on a shared plant with zero references and a centred box (lqmpc_probe.h): a clipped roll
+    // of the PLANT under the first gain of the N-stage problem on it -- the closed loop every instance of the batch runs in
+    bool lin = c.x_ref || c.u_ref;
+    for (int k = 0; k < nu; ++k) lin = lin || (c.ub[k] + c.lb[k] != 0.0);
+    bool roll = !lin && !c.true_per_instance && c.At_sh && c.Bt_sh && nu <= 8 && (c.mode == lqmpc::MODE_ROLLOUT || c.mode == lqmpc::MODE_SWEEP);
+    std::vector<double> Kg((size_t)nu * nx, 0.0);
+    if (roll) roll = host_first_gain(nx, nu, N, c.At_sh, c.Bt_sh, c.Q, c.R, c.P, Kg.data());
+    p.so.Kg = put(roll ? Kg.data() : nullptr, nu * nx);
+    p.order_roll = roll ? 1 : 0;
     rc = ensure(h, h->shared, sh.size() * sizeof(double));
     if (rc) return rc;
     if (sh != h->shared_host) {

@@ -25,6 +25,7 @@ enum Mode : int { MODE_SOLVE = 0, MODE_ROLLOUT = 1, MODE_MAXVN = 2, MODE_PROBE =
 // whole batch: Q, R, P, lb, ub, x_ref (nx,N), u_ref (nu,N), A_true, B_true, x0s (nx,K).
 struct SharedOff {
     int Q, R, P, lb, ub, xref, uref, At, Bt, x0s;
+    int Kg;                               // the first gain of the N-stage problem on the shared plant (nu x nx): the order's roll (order_roll)
 };
 
 struct KParams {
@@ -33,6 +34,7 @@ struct KParams {
     int true_per_instance;
     int has_ref;
     int has_lin;                          // references or an off-centre box: the linear term has a constant part (host: has_ref || any lb + ub != 0)
+    int order_roll;                       // MODE_PROBE: key = the last step of a clipped roll of the shared plant under so.Kg whose input saturates
     int max_iter, polish, presolve, warm_start;
     double eps, tau, z0_scale;
     long long Bsz;
