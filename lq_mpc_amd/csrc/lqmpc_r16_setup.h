@@ -111,24 +111,33 @@ struct RollArgs {
 };
 __device__ __forceinline__ RollArgs roll_args(const KParams &p) { return RollArgs{p.x0, p.so.lb, p.so.ub, p.has_lin == 0}; }
 
-// Zero-padded loads of one instance's model (instance-minor arrays or the probe's instance-major records) and of the shared weights
+// Zero-padded loads of one instance's model (instance-minor arrays or the probe's instance-major records) and of the shared weights.
+// Both layouts are "base + element index x stride" (records: stride 1 from rec + bg REC; arrays: stride Bsz from A + bg, B + bg), so an
+// element costs one 64-bit multiply-add whichever layout the call uses (the per-element choice between two address computations
+// was a sixth of the set-up's vector instructions).
 template <int NX, int NU>
 struct ModelLd {
     const SetupArgs &p;
     long long bg;
+    const double *bA, *bB;
+    long long se;
     static constexpr int REC = NX * NX + NX * NU + NX;
+    __device__ __forceinline__ ModelLd(const SetupArgs &p_, long long bg_) : p(p_), bg(bg_)
+    {
+        bA = p.rec ? p.rec + bg * REC : p.A + bg;
+        bB = p.rec ? p.rec + bg * REC + NX * NX : p.B + bg;
+        se = p.rec ? 1 : p.Bsz;
+    }
     __device__ __forceinline__ double A(int a, int k) const
     {
         const bool v = a < NX && k < NX;
-        const int aa = v ? a : 0, kk = v ? k : 0;
-        const double x = p.rec ? p.rec[bg * REC + aa * NX + kk] : p.A[(long long)(aa * NX + kk) * p.Bsz + bg];
+        const double x = bA[(long long)(v ? a * NX + k : 0) * se];
         return v ? x : 0.0;
     }
     __device__ __forceinline__ double B(int a, int k) const
     {
         const bool v = a < NX && k >= 0 && k < NU;
-        const int aa = v ? a : 0, kk = v ? k : 0;
-        const double x = p.rec ? p.rec[bg * REC + NX * NX + aa * NU + kk] : p.B[(long long)(aa * NU + kk) * p.Bsz + bg];
+        const double x = bB[(long long)(v ? a * NU + k : 0) * se];
         return v ? x : 0.0;
     }
     __device__ __forceinline__ double S(int o, int a, int k, int dim) const
@@ -167,7 +176,7 @@ __device__ __attribute__((noinline)) void r16_build_P(const SetupArgs p, long lo
     const int lane = threadIdx.x, r = lane >> 4, c = lane & 3, g = (lane >> 2) & 3;
     wg::ldsd *Pp = Lg + oP;
     const int dP = oD - oP;
-    const ModelLd<NX, NU> ld{p, bg};
+    const ModelLd<NX, NU> ld(p, bg);
     double A[TX][TX], At[TX][TX], Q[TX][TX], Lt[TX][TX];
     double Bpl[SPT][TX];                                              // B in column block q of a tile
 #pragma unroll
@@ -304,7 +313,7 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
     wg::ldsd *Wp = Lg + oW, *Gs = Lg + oG;
     const int dW = oD - oW, dG = oD - oG;
     // ---- the model and the weights as register matrices (tiles [a][b]: rows 4a.., columns 4b..) ----
-    const ModelLd<NX, NU> ld{p, bg};
+    const ModelLd<NX, NU> ld(p, bg);
     double A[TX][TX], Q[TX][TX], S[TX][TX];
     double Bp[TX], nBt[TX];                                           // B (n_x x 4, columns 0..NU-1) by row tiles; -(B tile)' as register matrices
     double Bpl[SPT][TX], nBpl[SPT][TX];                               // B (and -B) in column block q of a tile
