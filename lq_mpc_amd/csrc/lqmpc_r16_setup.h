@@ -48,6 +48,7 @@ struct SetupT {
     static constexpr int NT = (npad + 3) / 4;                 // 4-row tiles of the npad x npad matrices
     static constexpr int SPT = 4 / NUP;                       // stages per tile
     static constexpr int NTM = (LPI == 16) ? NT : (NT + 3) / 4;   // tile registers: LPI = 64 deals tile I to block I % 4, register I / 4
+    static constexpr bool EXACT_TILES = (NUP == NU) && (n % 4 == 0);   // the 4-row tiles cover exactly the rows of the problem
     static constexpr int tile_of_stage(int j) { return (j * NUP) / 4; }
     static constexpr int off_of_stage(int j) { return (j * NUP) % 4; }
     // has tile I rows of a stage beyond j (i.e. is its rho non-zero when stage j is processed)?
@@ -154,6 +155,14 @@ template <class T, bool PACKED>
 __device__ __forceinline__ void store_tile(wg::ldsd *M, int dummy, int I, int J, double val, bool on, int r, int c)
 {
     constexpr int LDW = T::n + 1;
+    if constexpr (PACKED && T::EXACT_TILES) {
+        // every row of every tile is a row of the problem: the packed index is r (r + 1) / 2 + c (once per lane) + r (4 I) + a constant of
+        // the tile, and only the diagonal tiles have an upper triangle to skip (two instructions per tile instead of seven)
+        const int idx = (r * (r + 1) / 2 + c) + r * (4 * I) + (8 * I * I + 2 * I + 4 * J);
+        const bool low = on && (J < I || c <= r);
+        M[low ? idx : dummy] = val;
+        return;
+    }
     const int row = T::row_of(4 * I + r), col = T::row_of(4 * J + c);
     const bool low = on && row >= 0 && col >= 0 && col <= row;
     if constexpr (PACKED) M[low ? row * (row + 1) / 2 + col : dummy] = val;
