@@ -1097,10 +1097,10 @@ __device__ __forceinline__ void r16_body(const KParams &p, double *lds_raw, long
             Br_[k] = p.true_per_instance ? p.Bt[(long long)(ia * NU + k) * Bsz + bq] : sh[p.so.Bt + ia * NU + k];
             Rr_[k] = sh[p.so.R + ik * NU + k];
         }
-        // one instance per wavefront, built for two waves per SIMD: my rows live in the LDS constants region (the open-loop part is done
-        // with it), read per step.  Four instances per wavefront keep them in registers (24 at C3: the free steps of a rollout read
-        // nothing from LDS; C3 0.325 -> 0.318 ms)
-        constexpr bool ROWS_IN_LDS = OCC == 2 && LPI == 64;
+        // my rows: in registers up to 24 of them (C3 0.325 -> 0.318 ms, C4 4.30 -> 4.14 ms: the free steps of a rollout read nothing from
+        // LDS); the larger state dimensions of the one-instance-per-wavefront build keep them in the LDS constants region (the open-loop
+        // part is done with it) and read them per step
+        constexpr bool ROWS_IN_LDS = OCC == 2 && LPI == 64 && 2 * NX + 2 * NU > 12;
         constexpr int RW = 2 * NX + 2 * NU;
         static_assert((NX > NU ? NX : NU) * RW <= C::CN + (C::CN & 1), "the per-lane rows fit the constants region");
         ldsd *myc = L + C::oC + ((i < NX || i < NU) ? i : 0) * RW;
