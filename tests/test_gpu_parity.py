@@ -356,6 +356,40 @@ def test_difficulty_ordering_is_transparent(solver, golden_dir):
     assert rel(r1["J_T"][idx], ref["J_T"]) < TIGHT
 
 
+def test_both_order_keys_are_transparent(solver):
+    """The order has two keys (lqmpc_probe.h): the clipped roll of the shared plant (zero references, centred box) and the
+    free-response gradient for everything else (per-instance plants, an off-centre box, T beyond the roll's 31 steps is capped).
+    Whatever the key, ordering on / off gives the same rollouts; checked on the 16-lane-row kernel and against the oracle."""
+    b = synth.make_batch(3, Bsz=2048 + 5)
+    rng = np.random.default_rng(11)
+    At = np.ascontiguousarray(b["A_true"][:, :, None] + 1e-3 * rng.standard_normal((4, 4, b["Bsz"])))
+    Bt = np.ascontiguousarray(b["B_true"][:, :, None] + 1e-3 * rng.standard_normal((4, 2, b["Bsz"])))
+    cases = {
+        "shared plant": (b["lb"], b["ub"], b["A_true"], b["B_true"], 20),
+        "shared plant, T = 40": (b["lb"], b["ub"], b["A_true"], b["B_true"], 40),
+        "per-instance plants": (b["lb"], b["ub"], At, Bt, 12),
+        "off-centre box": (b["lb"] - 0.03, b["ub"] - 0.03, b["A_true"], b["B_true"], 12),
+    }
+    idx = rng.choice(b["Bsz"], 256, replace=False)
+    try:
+        for name, (lb, ub, A_t, B_t, T) in cases.items():
+            a = (b["N"], b["A"], b["B"], b["Q"], b["R"], b["P"], lb, ub)
+            solver.set_options(order=0)
+            r0 = solver.rollout_batch(T, *a, b["x0"], A_t, B_t)
+            solver.set_options(order=1)
+            r1 = solver.rollout_batch(T, *a, b["x0"], A_t, B_t)
+            assert "r16" in solver.last_kernel(), name
+            assert np.all(r0["status"] == 0) and np.all(r1["status"] == 0), name
+            assert np.array_equal(r0["J_T"], r1["J_T"]) and np.array_equal(r0["iters"], r1["iters"]), name
+            per = A_t.ndim == 3
+            ref = orc.rollout_batch(T, b["N"], np.ascontiguousarray(b["A"][:, :, idx]), np.ascontiguousarray(b["B"][:, :, idx]), b["Q"], b["R"], b["P"],
+                                    lb, ub, np.ascontiguousarray(b["x0"][:, idx]),
+                                    np.ascontiguousarray(A_t[:, :, idx]) if per else A_t, np.ascontiguousarray(B_t[:, :, idx]) if per else B_t)
+            assert rel(r1["J_T"][idx], ref["J_T"]) < TIGHT, name
+    finally:
+        solver.set_options(order=-1)
+
+
 # ---------------- stress: random shapes of cost, box, conditioning on the specialised shapes ----------------
 WG_SHAPES = [(8, 4, 30), (6, 3, 15), (16, 2, 17), (3, 2, 64), (5, 1, 33)]     # n = 120, 45, 34, 128, 33
 PREBUILT = [(4, 2, 10), (2, 1, 10), (2, 1, 5), (2, 1, 7), (2, 1, 20), (2, 1, 30), (4, 2, 20)]
