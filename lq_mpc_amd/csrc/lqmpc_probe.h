@@ -57,7 +57,7 @@ __device__ __forceinline__ void probe_body(const KParams &p)
         // input saturates (the MPC steps up to there are the constrained ones), 16ths of a margin behind it: 1 - 1/m at that step,
         // or m at x0 where no step saturates (m = max_k |u_k| / h_k).  Wave-steps with a constrained instance at C3, four instances
         // per wavefront in this order: 15.1 % (the free-response key below: 18.3 %, the true count of constrained steps: 14.8 %,
-        // natural order: 29.3 %; hard mix 67.3 / 78.6 / 66.2 / 91.5 %: tools/proto/order_keys.py).  ~1000 FMAs per instance on
+        // natural order: 29.3 %; hard mix 67.3 / 78.6 / 66.2 / 91.5 %: tests/dev/order_keys.py).  ~1000 FMAs per instance on
         // scalar operands.
         double At[NX][NX], Bt[NX][NU], Kg[NU][NX], hk[NU], nhk[NU], hinv[NU];
 #pragma unroll
