@@ -425,7 +425,9 @@ static int prepare(lqmpc_handle *h, const Call &c, KParams &p)
     // of the PLANT under the first gain of the N-stage problem on it -- the closed loop every instance of the batch runs in
     bool lin = c.x_ref || c.u_ref;
     for (int k = 0; k < nu; ++k) lin = lin || (c.ub[k] + c.lb[k] != 0.0);
-    bool roll = !lin && !c.true_per_instance && c.At_sh && c.Bt_sh && nu <= 8 && (c.mode == lqmpc::MODE_ROLLOUT || c.mode == lqmpc::MODE_SWEEP);
+    // (only where an order can be built at all: small batches skip the host's Riccati steps)
+    const bool may_order = h->opt.order > 0 || (h->opt.order < 0 && c.T >= 4 && c.Bsz >= 1024);
+    bool roll = may_order && !lin && !c.true_per_instance && c.At_sh && c.Bt_sh && nu <= 8 && (c.mode == lqmpc::MODE_ROLLOUT || c.mode == lqmpc::MODE_SWEEP);
     std::vector<double> Kg((size_t)nu * nx, 0.0);
     if (roll) roll = host_first_gain(nx, nu, N, c.At_sh, c.Bt_sh, c.Q, c.R, c.P, Kg.data());
     p.so.Kg = put(roll ? Kg.data() : nullptr, nu * nx);

@@ -349,7 +349,7 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
     double rho[NTM][TX];                          // rho' of the rows of tile I (n_x x 4: column = row of the tile), by row tiles
     // T(:, M)' and (T(:, M) D_M^-1 / 2)' of the current column tile M on the rows of every tile from M on: register-matrix row
     // q NUP + u <-> column u of stage M SPT + q; filled stage by stage (the accumulator operand), used once per column tile
-    double TtA[NTM], TDA[NTM];
+    double TtA[NTM], TDA[NTM], Dh = 0.0;
     double KT[ROLL ? N : 1][TX];                  // K_j' (n_x x 4, by row tiles) of every stage, for the roll after the sweep
 #pragma unroll
     for (int m = 0; m < NTM; ++m) {
@@ -454,17 +454,20 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
 #pragma unroll
         for (int a = 0; a < TX; ++a) {
             Ktp[a] = mm4(K[a], SH);                                   // K' in the columns of stage j
-            nBRt[a] = mm4(nBt[a], R1h);                               // -(1/2) B Re^-1 in the columns of stage j
+            if constexpr (LPI == 64) nBRt[a] = mm4(nBt[a], R1h);      // -(1/2) B Re^-1 in the columns of stage j
         }
         if constexpr (LPI == 16) {
+            // T(:, M)' stage by stage; (T(:, M) D_M^-1 / 2)' = Dh T(:, M)' once per column tile, Dh = the blocks Re_j^-1 / 2 of its stages on
+            // the diagonal (one product per tile and column tile instead of one per tile and stage)
+            Dh = (first_of_tile ? 0.0 : Dh) + Rqq;
             sfor<Ij, NT>([&](auto Ic) {
                 constexpr int I = decltype(Ic)::value;
                 const double cT = (first_of_tile ? 0.0 : TtA[I]) + (I == Ij ? Iq : 0.0);
-                const double cD = (first_of_tile ? 0.0 : TDA[I]) + (I == Ij ? Rqq : 0.0);
-                if constexpr (T::live(I, j)) { TtA[I] = dotc(nBpl[q], rho[I], cT); TDA[I] = dotc(nBRt, rho[I], cD); }
-                else { TtA[I] = cT; TDA[I] = cD; }                  // (I == Ij and no row of a later stage in the tile yet)
+                if constexpr (T::live(I, j)) TtA[I] = dotc(nBpl[q], rho[I], cT);
+                else TtA[I] = cT;                                   // (I == Ij and no row of a later stage in the tile yet)
             });
             if constexpr (q == 0) {
+                sfor<Ij, NT>([&](auto Ic) { constexpr int I = decltype(Ic)::value; TDA[I] = mm4(Dh, TtA[I]); });
                 sfor<Ij, NT>([&](auto Ic) {
                     constexpr int I = decltype(Ic)::value;
                     sfor<Ij, I + 1>([&](auto Jc) {
