@@ -389,7 +389,7 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
         constexpr int j = N - 1 - decltype(jc)::value;
         constexpr int Ij = T::tile_of_stage(j), off = T::off_of_stage(j), q = off / NUP;
         constexpr bool first_of_tile = (j == N - 1) || (q == SPT - 1);        // (backward: the highest stage of column tile Ij comes first)
-        double SA[TX][TX], SB[TX], F[TX], K[TX], Acl[TX][TX], Ktp[TX], nBRt[TX];
+        double SA[TX][TX], SB[TX], F[TX], K[TX], Acl[TX][TX], Ktp[TX];
 #pragma unroll
         for (int a = 0; a < TX; ++a) {
 #pragma unroll
@@ -454,12 +454,11 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
 #pragma unroll
         for (int a = 0; a < TX; ++a) {
             Ktp[a] = mm4(K[a], SH);                                   // K' in the columns of stage j
-            if constexpr (LPI == 64) nBRt[a] = mm4(nBt[a], R1h);      // -(1/2) B Re^-1 in the columns of stage j
         }
+        // T(:, M)' stage by stage; (T(:, M) D_M^-1 / 2)' = Dh T(:, M)' once per column tile, Dh = the blocks Re_j^-1 / 2 of its stages on the
+        // diagonal (one product per tile and column tile instead of one per tile and stage)
+        Dh = (first_of_tile ? 0.0 : Dh) + Rqq;
         if constexpr (LPI == 16) {
-            // T(:, M)' stage by stage; (T(:, M) D_M^-1 / 2)' = Dh T(:, M)' once per column tile, Dh = the blocks Re_j^-1 / 2 of its stages on
-            // the diagonal (one product per tile and column tile instead of one per tile and stage)
-            Dh = (first_of_tile ? 0.0 : Dh) + Rqq;
             sfor<Ij, NT>([&](auto Ic) {
                 constexpr int I = decltype(Ic)::value;
                 const double cT = (first_of_tile ? 0.0 : TtA[I]) + (I == Ij ? Iq : 0.0);
@@ -490,9 +489,9 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
                 constexpr int m = decltype(mc)::value;
                 const bool mine = (4 * m + g == Ij);
                 TtA[m] = dotc(nBpl[q], rho[m], (first_of_tile ? 0.0 : TtA[m]) + (mine ? Iq : 0.0));
-                TDA[m] = dotc(nBRt, rho[m], (first_of_tile ? 0.0 : TDA[m]) + (mine ? Rqq : 0.0));
             });
             if constexpr (q == 0) {
+                sfor<m0, NTM>([&](auto mc) { constexpr int m = decltype(mc)::value; TDA[m] = mm4(Dh, TtA[m]); });
                 sfor<m0, NTM>([&](auto mc) {
                     constexpr int m = decltype(mc)::value;
                     sfor<m0, m + 1>([&](auto nc) {
