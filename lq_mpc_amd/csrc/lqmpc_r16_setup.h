@@ -417,7 +417,7 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
         const double R0 = small_inverse<NUP>(Re, r, c);
 #pragma unroll
         for (int b = 0; b < TX; ++b) K[b] = mm4(R0, F[b]);
-        if constexpr (ROLL) {
+        if constexpr (ROLL && off != 0) {                             // (off == 0: K' is Ktp below, as it stands)
 #pragma unroll
             for (int b = 0; b < TX; ++b) KT[j][b] = mm4(F[b], R0);
         }
@@ -454,6 +454,7 @@ __device__ __forceinline__ void r16_setup_mfma(const SetupArgs &p, long long bg,
 #pragma unroll
         for (int a = 0; a < TX; ++a) {
             Ktp[a] = mm4(K[a], SH);                                   // K' in the columns of stage j
+            if constexpr (ROLL && off == 0) KT[j][a] = Ktp[a];
         }
         // T(:, M)' stage by stage; (T(:, M) D_M^-1 / 2)' = Dh T(:, M)' once per column tile, Dh = the blocks Re_j^-1 / 2 of its stages on the
         // diagonal (one product per tile and column tile instead of one per tile and stage)
